@@ -1,0 +1,296 @@
+/*
+ * pimgpu.h -- C-ABI of the MI355X path-tracing hot path (libpimgpu.so).
+ *
+ * This is the ONE process/device boundary of the build: plain C, plain
+ * pointers and sizes, int status codes.  Everything above it is host C that
+ * mirrors Pim's own path-tracer API (pim_amd/host/pim_host.h); everything
+ * below it is hand-written HIP for gfx950.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the Pim source tree, src/...).
+ *
+ * Conventions
+ *   - every function returns PIMGPU_OK (0) or a negative PIMGPU_E_* code;
+ *     pimgpu_last_error() returns a human readable message for the calling
+ *     thread's last failure (the reference has no error codes: NULL scene /
+ *     Con_Logf, path_tracer.c:389-396,645-651,1085-1089);
+ *   - all pointers are caller owned; "host" pointers are ordinary host memory,
+ *     "dev" pointers are device (HBM) addresses obtained by the caller
+ *     (hipMalloc / torch);
+ *   - calls are synchronous from one host thread, like the reference's
+ *     main-thread entry points (path_tracer.h:67-103);
+ *   - float4 arrays are 4 packed floats per element, float3 3, float2 2.
+ */
+#ifndef PIMGPU_H
+#define PIMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIMGPU_OK            0
+#define PIMGPU_E_INVALID    -1   /* bad argument (NULL, negative size, shape mismatch) */
+#define PIMGPU_E_DEVICE     -2   /* HIP runtime error / no gfx950 device */
+#define PIMGPU_E_NOMEM      -3   /* hipMalloc failed */
+#define PIMGPU_E_STATE      -4   /* call order violated (not initialised ...) */
+#define PIMGPU_E_LIMIT      -5   /* size beyond a documented maximum */
+
+/* MatFlag bits, rendering/material.h:8-20 */
+#define PIM_MATFLAG_EMISSIVE   (1u << 0)
+#define PIM_MATFLAG_SKY        (1u << 1)
+#define PIM_MATFLAG_REFRACTIVE (1u << 5)
+
+/* PtHitType, rendering/path_tracer.h:15-22 */
+#define PIM_HIT_NOTHING  0
+#define PIM_HIT_BACKFACE 1
+#define PIM_HIT_TRIANGLE 2
+
+/* texture formats the path reads (rendering/sampler.h:370-392) */
+#define PIM_TEX_RGBA8 0   /* R8G8B8A8 with the cubic sRGB fit decode */
+#define PIM_TEX_XY16  1   /* short2 tangent-space normal */
+
+/* Material, rendering/material.h:22-31; TextureId -> index into textures[], -1 = none */
+typedef struct PimMaterial
+{
+    int32_t  albedo;
+    int32_t  rome;
+    int32_t  normal;
+    uint32_t flags;
+    float    meanFreePath[4];
+    float    ior;
+    float    bumpiness;
+    float    _pad[2];
+} PimMaterial;                       /* 48 bytes */
+
+/* Texture, rendering/texture.h (size, texels, format) */
+typedef struct PimTexture
+{
+    int32_t     width;
+    int32_t     height;
+    int32_t     format;              /* PIM_TEX_* */
+    int32_t     _pad;
+    const void* texels;              /* host, width*height*4 bytes */
+} PimTexture;
+
+/* user-facing part of PtMediaDesc, path_tracer.c:91-111; derived fields
+ * (constantMu, noiseMu, noiseRange, rcpMajorant) are recomputed by the library
+ * as media_desc_update does (path_tracer.c:1963-1987). */
+typedef struct PimMediaDesc
+{
+    float   constantColor[4];
+    float   noiseColor[4];
+    float   constantMfp;
+    float   noiseMfp;
+    float   absorption;
+    int32_t noiseOctaves;
+    float   noiseGain;
+    float   noiseLacunarity;
+    float   noiseFreq;
+    float   noiseScale;
+    float   noiseHeight;
+    float   phaseDirA;
+    float   phaseDirB;
+    float   phaseBlend;
+} PimMediaDesc;
+
+/* The flattened PtScene (path_tracer.c:122-166) + everything the reference pulls
+ * from global singletons at PtScene_Update time: texture table,
+ * sky cubemap, g_BrdfLut, cv_pt_dist_meters. */
+typedef struct PimSceneDesc
+{
+    int32_t            vertCount;        /* multiple of 3; primID*3 == iVert */
+    int32_t            matCount;
+    int32_t            texCount;
+    int32_t            skySize;          /* 0 = no sky cubemap */
+    const float*       positions;        /* float4[vertCount], world space, w=1 */
+    const float*       normals;          /* float4[vertCount] */
+    const float*       uvs;              /* float2[vertCount] */
+    const int32_t*     matIds;           /* i32[vertCount] */
+    const PimMaterial* materials;        /* [matCount] */
+    const PimTexture*  textures;         /* [texCount] */
+    const float*       skyFaces[6];      /* float3[skySize^2] per Cubeface (cubemap.h:16-26) */
+    const float*       brdfLut;          /* float2[brdfLutSize^2] (lighting.h:45-55) */
+    int32_t            brdfLutSize;
+    int32_t            emissiveAttempts; /* 1000 in the reference (path_tracer.c:853) */
+    float              metersPerCell;    /* cv_pt_dist_meters, 1.5 (cvars.c:208-216) */
+    uint32_t           seed;             /* build-defined seed of the set-up RNG streams */
+    PimMediaDesc       media;
+} PimSceneDesc;
+
+typedef struct PimSceneInfo
+{
+    int32_t vertCount;
+    int32_t triCount;
+    int32_t matCount;
+    int32_t emissiveCount;
+    int32_t gridSize[3];
+    int32_t gridLen;
+    int32_t activeCells;          /* cells with a Dist1D (length != 0) */
+    int32_t bvhNodeCount;
+    int32_t bvhMaxDepth;
+    float   boundsLo[3];
+    float   boundsHi[3];
+    float   bvhBuildMs;           /* device time of the last BVH build */
+    float   sceneSetupMs;         /* emissives + light grid */
+} PimSceneInfo;
+
+/* PtRayHit, rendering/path_tracer.h:24-31 (48 bytes) */
+typedef struct PimRayHit
+{
+    float    wuvt[4];
+    float    normal[4];
+    int32_t  type;                /* PIM_HIT_* */
+    int32_t  iVert;
+    uint32_t flags;
+    int32_t  _pad;
+} PimRayHit;
+
+/* PtResult, rendering/path_tracer.h:54-59 (36 bytes) */
+typedef struct PimResult
+{
+    float color[3];
+    float albedo[3];
+    float normal[3];
+} PimResult;
+
+/* Camera, rendering/camera.h:8-15 */
+typedef struct PimCamera
+{
+    float position[4];
+    float rotation[4];            /* quaternion xyzw */
+    float zNear;
+    float zFar;
+    float fovy;                   /* degrees */
+    float _pad;
+} PimCamera;
+
+/* PtDofInfo, rendering/path_tracer.h:33-42 */
+typedef struct PimDofInfo
+{
+    float   aperture;
+    float   focalLength;
+    int32_t bladeCount;
+    float   bladeRot;
+    float   focalPlaneCurvature;
+    float   autoFocusSpeed;
+    int32_t autoFocus;
+} PimDofInfo;
+
+/* build-side extensions of one Pt_Trace call (D1, D2) */
+typedef struct PimTraceParams
+{
+    float    sampleWeight;        /* PtTrace.sampleWeight = 1/sampleCount, path_tracer.h:51 */
+    float    frameDt;             /* Time_Deltaf() fed to DofUpdate, path_tracer.c:2497 */
+    uint32_t sampleIndex;         /* index of this sample (frame); seeds the per-pixel stream */
+    uint32_t seed;
+    int32_t  maxBounces;          /* <=0: reference behaviour (666, RR only) */
+    int32_t  updateDists;         /* !=0: run UpdateDists first as PtScene_Update does (:1034) */
+} PimTraceParams;
+
+/* one lightmap page: the single allocation of Lightmap_New (lightmap.c:81-110):
+ * [5][S*S] float4 probes | [S*S] float3 position | [S*S] float3 normal | [S*S] float sampleCounts */
+typedef struct PimLightmapPage
+{
+    float* block;                 /* host pointer to the page's allocation */
+} PimLightmapPage;
+
+typedef struct PimScene PimScene;  /* opaque, like PtScene (path_tracer.h:13) */
+typedef struct PimTrace PimTrace;  /* device-side PtTrace (path_tracer.h:44-52) */
+
+/* ---- library ------------------------------------------------------------- */
+
+/* PtSys_Init / PtSys_Shutdown (path_tracer.c:421-446): select the HIP device. */
+int pimgpu_init(int device);
+int pimgpu_shutdown(void);
+const char* pimgpu_last_error(void);
+
+/* ---- scene --------------------------------------------------------------- */
+
+/* PtScene_New -> PtScene_Init (path_tracer.c:1039-1049,1083-1093):
+ * upload, SetupEmissives (:845-883), RtcNewScene/rtcCommitScene (:618-690, replaced by the
+ * GPU LBVH build), SetupLightGrid (:885-1009). */
+int pimgpu_scene_create(const PimSceneDesc* desc, PimScene** out);
+/* PtScene_Del (path_tracer.c:1095-1102) */
+int pimgpu_scene_destroy(PimScene* scene);
+/* rtcCommitScene alone (path_tracer.c:687): full BVH rebuild from the resident positions */
+int pimgpu_scene_rebuild_bvh(PimScene* scene);
+/* UpdateDists (path_tracer.c:2471-2483): Dist1D_Update on every grid cell */
+int pimgpu_scene_update_dists(PimScene* scene);
+/* igText lines of PtScene_Gui (path_tracer.c:1104-1115) as data */
+int pimgpu_scene_info(const PimScene* scene, PimSceneInfo* out);
+/* parity probes of the scene set-up: any pointer may be NULL.
+ *   vertToEmit i32[vertCount], emitToVert i32[emissiveCount],
+ *   cellLength i32[gridLen] (Dist1D.length, 0 = skipped cell),
+ *   pdf float[gridLen*E], cdf float[gridLen*(E+1)], live u32[gridLen*E] */
+int pimgpu_scene_download_lights(const PimScene* scene,
+    int32_t* vertToEmit, int32_t* emitToVert, int32_t* cellLength,
+    float* pdf, float* cdf, uint32_t* live);
+
+/* ---- rays ---------------------------------------------------------------- */
+
+/* batched Pt_Intersect (path_tracer.c:1466-1474, pt_intersect_local :1421-1464);
+ * ro/rd float4[n] (w ignored), tNear/tFar float[n]; host pointers. */
+int pimgpu_intersect(const PimScene* scene, const float* ro, const float* rd,
+    const float* tNear, const float* tFar, int32_t n, PimRayHit* out);
+/* same with device pointers (rays and hits stay in HBM); hits are the raw closest-hit
+ * records int4-sized {primID, t, u, v} (primID -1 = miss), the layout the wavefront
+ * integrator consumes. */
+int pimgpu_intersect_dev(const PimScene* scene, const void* roDev, const void* rdDev,
+    const void* tNearDev, const void* tFarDev, int32_t n, void* hitsDev);
+
+/* batched Pt_TraceRay (path_tracer.c:2306-2416); stream i is seeded Pcg4(i, sampleIndex, seed, k) */
+int pimgpu_trace_rays(PimScene* scene, const float* ro, const float* rd, int32_t n,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, PimResult* out);
+/* Pt_RayGen (path_tracer.c:2596-2644): count uniform-sphere paths from origin;
+ * colors/directions float4[count], host. */
+int pimgpu_raygen(PimScene* scene, const float* origin, int32_t count,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces,
+    float* colors, float* directions);
+
+/* ---- image --------------------------------------------------------------- */
+
+/* PtTrace_New / PtTrace_Del (path_tracer.c:1117-1139): zeroed device buffers */
+int pimgpu_trace_create(int32_t width, int32_t height, PimTrace** out);
+int pimgpu_trace_destroy(PimTrace* trace);
+int pimgpu_trace_clear(PimTrace* trace);
+/* Pt_Trace (path_tracer.c:2557-2585): [UpdateDists] + DofUpdate (dof is updated in place,
+ * :2485-2503) + TraceFn over W*H pixels (:2514-2554), one sample per pixel, running mean. */
+int pimgpu_trace_image(PimScene* scene, PimTrace* trace, const PimCamera* camera,
+    PimDofInfo* dof, const PimTraceParams* params);
+/* copy the running-mean buffers to host float3[W*H] arrays (any may be NULL);
+ * the reference's callers read PtTrace.color/albedo/normal on the host (render_system.c:306-352) */
+int pimgpu_trace_download(const PimTrace* trace, float* color, float* albedo, float* normal);
+/* device addresses of the float3 buffers (for torch.distributed reduce without a host copy) */
+int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDev, void** normalDev);
+/* CalcStdDev (render_system.c:1374-1394) on the device colour buffer */
+int pimgpu_trace_stddev(const PimTrace* trace, float* meanOut, float* stddevOut);
+/* statistics of the last pimgpu_trace_image call: rays traced (extension, shadow, other), bounces */
+typedef struct PimTraceStats
+{
+    uint64_t extensionRays;
+    uint64_t shadowRays;
+    uint64_t otherRays;         /* media NEE + refraction thickness + autofocus */
+    uint64_t paths;
+    int32_t  bounces;           /* bounce iterations launched */
+    float    traceMs;           /* device time inside the traversal kernels */
+    float    totalMs;           /* device time of the whole call */
+} PimTraceStats;
+int pimgpu_trace_stats(const PimTrace* trace, PimTraceStats* out);
+
+/* ---- lightmap ------------------------------------------------------------ */
+
+/* LmPack_Bake (lightmap.c:1204-1223, BakeFn :1125-1201) on host pages of the exact
+ * reference layout; pages are updated in place. texelBegin/texelEnd select a
+ * sub-range of the lmCount*lmSize^2 work items (texel-tile sharding). */
+int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCount,
+    int32_t lmSize, float texelsPerMeter, float timeSlice, int32_t spp,
+    uint32_t passIndex, uint32_t seed, int32_t maxBounces,
+    int64_t texelBegin, int64_t texelEnd);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PIMGPU_H */

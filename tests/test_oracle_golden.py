@@ -1,0 +1,75 @@
+"""Pins the CPU oracle's math restatement (oracle/orc_math.h, Dist1D in oracle/pim_oracle.c)
+against golden vectors produced by the REFERENCE's own headers.
+
+tests/golden/ref_math.bin is written by oracle/ref_golden.c, which #includes
+/root/reference/src/math/*.h, common/random.h, rendering/sampler.h, rendering/cubemap.h and
+links math/dist1d.c, math/sphgauss.c, rendering/cubemap.c where they lie (oracle/Makefile
+target `golden`, container only).  Both sides are built -O2 -ffp-contract=off without
+-ffast-math, so the bar is BIT-EXACT on every word (floats compared by bit pattern)."""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests.util import load_oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "ref_math.bin")
+
+
+def read_records(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    magic, version, nrec = struct.unpack_from("<III", data, 0)
+    assert magic == 0x474D4950 and version == 1
+    off = 12
+    recs = []
+    for _ in range(nrec):
+        (name_len,) = struct.unpack_from("<I", data, off)
+        off += 4
+        name = data[off:off + name_len].decode()
+        off += (name_len + 3) & ~3
+        ncases, nin, nout = struct.unpack_from("<III", data, off)
+        off += 12
+        words = np.frombuffer(data, dtype=np.uint32, count=ncases * (nin + nout), offset=off).reshape(ncases, nin + nout)
+        off += 4 * ncases * (nin + nout)
+        recs.append((name, nin, nout, words.copy()))
+    assert off == len(data)
+    return recs
+
+
+RECORDS = read_records(GOLDEN)
+
+
+def test_golden_file_covers_the_survey_list():
+    names = {r[0] for r in RECORDS}
+    # the pure functions of the path that must be pinned
+    for need in ["pcg1", "pcg2", "pcg3", "pcg4", "prng_seq", "NormalToTBN", "MapSquareToDisk",
+                 "SampleCosineHemisphere", "SampleGGXMicrofacet", "SampleBaryCoord", "SampleUnitSphere",
+                 "SampleUnitHemisphere", "SampleNGon", "SampleGaussPixelFilter", "SampleFreePath",
+                 "PowerHeuristic", "LightPdf", "GGXPdf", "F_Dielectric", "D_GTR", "V_SmithCorrelated",
+                 "Fd_Burley", "F_0_F_90", "AlbedoToTransmittance", "reflect3", "refract3",
+                 "GammaDecode_rgba8", "GammaEncode_rgba8", "UnpackEmission", "Bilinear", "Xy16ToNormalTs",
+                 "Cubemap_CalcUv", "Grid", "Dist1D_Bake_Sample", "Dist1D_Update", "SG_Accumulate6",
+                 "GradientNoise3", "FbmGradientNoise3", "MiePhase", "camera_basis", "trs_flatten"]:
+        assert need in names, need
+
+
+@pytest.mark.parametrize("rec", RECORDS, ids=[r[0] for r in RECORDS])
+def test_oracle_matches_reference_bits(rec):
+    name, nin, nout, words = rec
+    lib = load_oracle()
+    fn = getattr(lib, "orc_hook_" + name)
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    out = np.zeros(nout, dtype=np.uint32)
+    bad = []
+    for i in range(words.shape[0]):
+        inp = np.ascontiguousarray(words[i, :nin])
+        fn(inp.ctypes.data, out.ctypes.data)
+        exp = words[i, nin:]
+        if not np.array_equal(out, exp):
+            # +0 / -0 are the only tolerated difference in bit pattern (none observed)
+            bad.append((i, inp.view(np.float32).tolist(), out.view(np.float32).tolist(), exp.view(np.float32).tolist()))
+    assert not bad, f"{name}: {len(bad)} of {words.shape[0]} cases differ, first: {bad[0]}"
