@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdbool.h>
+#include "orc_libm.h"
 
 typedef struct { float x, y; } v2;
 typedef struct { float x, y, z; } v3;
@@ -58,7 +59,7 @@ ORC_INL float o_frac(float x) { return x - o_floor(x); }                        
 ORC_INL float o_lerp(float a, float b, float t) { return a + (b - a) * t; }                       /* :183 */
 ORC_INL float o_distance(float a, float b) { return o_abs(b - a); }                               /* :267 */
 ORC_INL float o_radians(float x) { return x * (ORC_TAU / 360.0f); }                               /* :74 */
-ORC_INL float o_gauss_invcdf(float p, float u, float s) { return u + s * sqrtf(-logf(o_max(1.0f - p, ORC_EPS))); } /* :299-302 */
+ORC_INL float o_gauss_invcdf(float p, float u, float s) { return u + s * sqrtf(-o_logf(o_max(1.0f - p, ORC_EPS))); } /* :299-302 */
 ORC_INL int32_t oi_min(int32_t a, int32_t b) { return a < b ? a : b; }
 ORC_INL int32_t oi_max(int32_t a, int32_t b) { return a > b ? a : b; }
 ORC_INL int32_t oi_clamp(int32_t x, int32_t lo, int32_t hi) { return oi_min(hi, oi_max(lo, x)); } /* :364 */
@@ -262,7 +263,7 @@ ORC_INL v4 quat_lookat(v4 forward, v4 up)                                       
 }
 
 /* ---- frustum: math/frustum.h:26-47 ---- */
-ORC_INL v2 proj_slope(float fovy, float aspect) { float t = tanf(fovy * 0.5f); return o2(aspect * t, t); }
+ORC_INL v2 proj_slope(float fovy, float aspect) { float t = o_tanf(fovy * 0.5f); return o2(aspect * t, t); }
 ORC_INL v4 proj_dir(v4 right, v4 up, v4 fwd, v2 slope, v2 coord)
 {
     coord = o2_mul(coord, slope);
@@ -358,7 +359,7 @@ ORC_INL v2 MapSquareToDisk(v2 Xi)                                               
     float b = 2.0f * Xi.y - 1.0f;
     if ((a * a) > (b * b)) { r = a; phi = (ORC_PI / 4.0f) * (b / a); }
     else { r = b; phi = (ORC_PI / 2.0f) - (ORC_PI / 4.0f) * (a / b); }
-    return o2(r * cosf(phi), r * sinf(phi));
+    return o2(r * o_cosf(phi), r * o_sinf(phi));
 }
 ORC_INL v4 SampleBaryCoord(v2 Xi)                                                                 /* :120-128 */
 {
@@ -375,8 +376,8 @@ ORC_INL v2 SampleNGon(v2 Xi, uint32_t side, uint32_t N, float rot)              
     const float R = ORC_TAU / N;
     const float a = rot + (1 + side) * R;
     const float b = rot + (2 + side) * R;
-    const v2 A = { cosf(a), sinf(a) };
-    const v2 B = { cosf(b), sinf(b) };
+    const v2 A = { o_cosf(a), o_sinf(a) };
+    const v2 B = { o_cosf(b), o_sinf(b) };
     return o2_blend(o2(0.0f, 0.0f), A, B, SampleBaryCoord(Xi));
 }
 ORC_INL v2 SamplePentagram(v2 Xi, uint32_t side)                                                  /* :141-156 */
@@ -388,15 +389,15 @@ ORC_INL v2 SamplePentagram(v2 Xi, uint32_t side)                                
     const float a = s + (1.0f + side) * R;
     const float b = s + (1.5f + side) * R;
     const float c = s + (2.0f + side) * R;
-    const v2 A = { q * cosf(a), q * sinf(a) };
-    const v2 B = { cosf(b), sinf(b) };
-    const v2 C = { q * cosf(c), q * sinf(c) };
+    const v2 A = { q * o_cosf(a), q * o_sinf(a) };
+    const v2 B = { o_cosf(b), o_sinf(b) };
+    const v2 C = { q * o_cosf(c), q * o_sinf(c) };
     return o2_bilerp(A, B, o2(0.0f, 0.0f), C, Xi);
 }
 ORC_INL v4 SphericalToCartesian(float cosTheta, float phi)                                        /* :158-165 */
 {
     float sinTheta = sqrtf(o_max(1.0f - cosTheta * cosTheta, 0.0f));
-    return o4(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta, 0.0f);
+    return o4(sinTheta * o_cosf(phi), sinTheta * o_sinf(phi), cosTheta, 0.0f);
 }
 ORC_INL v4 SampleUnitSphere(v2 Xi) { return SphericalToCartesian(Xi.y * 2.0f - 1.0f, ORC_TAU * Xi.x); } /* :168 */
 ORC_INL v4 SampleUnitHemisphere(v2 Xi) { return SphericalToCartesian(Xi.y, ORC_TAU * Xi.x); }     /* :176 */
@@ -420,11 +421,11 @@ ORC_INL v2 SampleGaussPixelFilter(v2 Xi, float stddev)                          
 {
     float angle = Xi.x * ORC_TAU;
     float radius = o_gauss_invcdf(Xi.y, 0.0f, stddev);
-    Xi.x = cosf(angle);
-    Xi.y = sinf(angle);
+    Xi.x = o_cosf(angle);
+    Xi.y = o_sinf(angle);
     return o2_muls(Xi, radius);
 }
-ORC_INL float SampleFreePath(float Xi, float mfp) { return -logf(o_max(1.0f - Xi, ORC_EPS)) * mfp; } /* :340 */
+ORC_INL float SampleFreePath(float Xi, float mfp) { return -o_logf(o_max(1.0f - Xi, ORC_EPS)) * mfp; } /* :340 */
 
 /* ---- BRDF terms: math/lighting.h ---- */
 ORC_INL float BrdfAlpha(float roughness) { return o_max(roughness * roughness, ORC_MIN_ALPHA); }   /* :57 */
@@ -462,14 +463,14 @@ ORC_INL v4 SigmaAFromReflectance(v4 albedo, float beta_n)                       
     float r4 = r3 * beta_n;
     float r5 = r4 * beta_n;
     float t = 5.969f - 0.215f * beta_n + 2.532f * r2 - 10.73f * r3 + 5.574f * r4 + 0.245f * r5;
-    v4 s = o4(logf(albedo.x), logf(albedo.y), logf(albedo.z), logf(albedo.w));
+    v4 s = o4(o_logf(albedo.x), o_logf(albedo.y), o_logf(albedo.z), o_logf(albedo.w));
     s = o4_divs(s, o_max(t, ORC_EPS));
     return o4_mul(s, s);
 }
 ORC_INL v4 AlbedoToTransmittance(v4 albedo, float roughness, float thickness)                     /* :208-212 */
 {
     v4 s = o4_muls(SigmaAFromReflectance(albedo, roughness), -thickness);
-    return o4(expf(s.x), expf(s.y), expf(s.z), expf(s.w));
+    return o4(o_expf(s.x), o_expf(s.y), o_expf(s.z), o_expf(s.w));
 }
 ORC_INL float D_GTR(float NoH, float alpha)                                                       /* :218-224 */
 {
@@ -687,7 +688,7 @@ ORC_INL float FbmGradientNoise3(v4 p, float lacunarity, float gain, int32_t octa
 }
 
 /* ---- spherical gaussians: math/sphgauss.h:21-35, sphgauss.c:19-58 ---- */
-ORC_INL float SG_BasisEval(v4 axis, v4 dir) { return expf(axis.w * (o4_dot3(dir, axis) - 1.0f)); }
+ORC_INL float SG_BasisEval(v4 axis, v4 dir) { return o_expf(axis.w * (o4_dot3(dir, axis) - 1.0f)); }
 ORC_INL void SG_Accumulate(float sampleWeight, v4 dir, v4 rad, const v4* axii, v4* amplitudes, int32_t length)
 {
     if (sampleWeight == 1.0f)

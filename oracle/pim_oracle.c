@@ -1039,7 +1039,7 @@ static void LightOnHit(OrcScene* s, v4 ro, v4 lum4, int32_t iVert)          /* :
 {
     float lum = o4_avglum(lum4);
     if (lum <= ORC_EPS) return;
-    float loglum = log2f(lum) - ORC_LOG2_EPS;
+    float loglum = o_log2f(lum) - ORC_LOG2_EPS;
     loglum = o_clamp(loglum, 0.0f, 46.0f);
     uint32_t amt = (uint32_t)(loglum * (0xff / 46.0f) + 0.5f);
     int32_t iGrid = grid_index(&s->grid, ro);
@@ -1564,7 +1564,7 @@ void orc_trace_image(OrcScene* s, float* color, float* albedo, float* normal, in
         other = 1;
         if (hit.type != PIM_HIT_NOTHING)
         {
-            float t = 1.0f - expf(-p->frameDt * dof->autoFocusSpeed);
+            float t = 1.0f - o_expf(-p->frameDt * dof->autoFocusSpeed);
             dof->focalLength = o_lerp(dof->focalLength, hit.wuvt[3], t);
         }
         _mm_setcsr(csr);

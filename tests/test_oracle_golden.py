@@ -73,3 +73,44 @@ def test_oracle_matches_reference_bits(rec):
             # +0 / -0 are the only tolerated difference in bit pattern (none observed)
             bad.append((i, inp.view(np.float32).tolist(), out.view(np.float32).tolist(), exp.view(np.float32).tolist()))
     assert not bad, f"{name}: {len(bad)} of {words.shape[0]} cases differ, first: {bad[0]}"
+
+
+def _ulp_diff(a_bits, b_bits):
+    """distance in units in the last place between two float32 bit patterns (monotone integer map)"""
+    a = a_bits.astype(np.int64)
+    b = b_bits.astype(np.int64)
+    a = np.where(a & 0x80000000, 0x80000000 - a, a)
+    b = np.where(b & 0x80000000, 0x80000000 - b, b)
+    return np.abs(a - b)
+
+
+# records whose outputs are all integers (must stay bit-exact in the portable variant too)
+_INTEGER_RECORDS = {"pcg1", "pcg2", "pcg3", "pcg4", "GammaEncode_rgba8"}
+
+
+@pytest.mark.parametrize("rec", RECORDS, ids=[r[0] for r in RECORDS])
+def test_portable_oracle_matches_reference_within_ulps(rec):
+    """liborc_p.so (portable sin/cos/log/log2/exp, oracle/orc_libm.h) against the same vectors.
+    Bar: every float word within 4 ulp of the reference or within 2e-6 absolute (sin/cos near a
+    zero crossing lose relative accuracy in any libm); integer words exact.  Records that use no
+    transcendental function come out bit-exact and are checked as such by the ulp bound."""
+    name, nin, nout, words = rec
+    lib = load_oracle(portable=True)
+    fn = getattr(lib, "orc_hook_" + name)
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    out = np.zeros(nout, dtype=np.uint32)
+    worst = 0
+    for i in range(words.shape[0]):
+        inp = np.ascontiguousarray(words[i, :nin])
+        fn(inp.ctypes.data, out.ctypes.data)
+        exp = words[i, nin:]
+        if np.array_equal(out, exp):
+            continue
+        assert name not in _INTEGER_RECORDS, f"{name}: integer record differs at case {i}"
+        of, ef = out.view(np.float32).astype(np.float64), exp.view(np.float32).astype(np.float64)
+        ulps = _ulp_diff(out, exp)
+        ok = (ulps <= 4) | (np.abs(of - ef) <= 2e-6) | (np.isnan(of) & np.isnan(ef))
+        assert ok.all(), f"{name} case {i}: got {of.tolist()} expected {ef.tolist()} (ulps {ulps.tolist()})"
+        worst = max(worst, int(ulps[ok & (np.abs(of - ef) > 2e-6)].max(initial=0)))
+    assert worst <= 4
