@@ -205,6 +205,8 @@ typedef struct PimTrace PimTrace;  /* device-side PtTrace (path_tracer.h:44-52) 
 int pimgpu_init(int device);
 int pimgpu_shutdown(void);
 const char* pimgpu_last_error(void);
+/* the hipStream_t every call of the library runs on (for HIP events around a call: bench.py's roofline leg) */
+void* pimgpu_stream(void);
 
 /* ---- scene --------------------------------------------------------------- */
 
@@ -239,6 +241,12 @@ int pimgpu_intersect(const PimScene* scene, const float* ro, const float* rd,
  * integrator consumes. */
 int pimgpu_intersect_dev(const PimScene* scene, const void* roDev, const void* rdDev,
     const void* tNearDev, const void* tFarDev, int32_t n, void* hitsDev);
+
+/* the traversal kernel alone on rays already packed the way it reads them: rayO = (origin.xyz, tNear),
+ * rayD = (direction.xyz, tFar), float4[n] each in HBM; hits as above.  This is the batched rtcIntersect1
+ * (path_tracer.c:470-486) the wavefront integrator issues twice per bounce, and the unit of the
+ * incoherent-ray benchmark. */
+int pimgpu_intersect_packed_dev(const PimScene* scene, const void* rayODev, const void* rayDDev, int32_t n, void* hitsDev);
 
 /* batched Pt_TraceRay (path_tracer.c:2306-2416); stream i is seeded Pcg4(i, sampleIndex, seed, k) */
 int pimgpu_trace_rays(PimScene* scene, const float* ro, const float* rd, int32_t n,

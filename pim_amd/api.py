@@ -1,0 +1,266 @@
+"""ctypes mirror of include/pimgpu.h and a thin loader for pim_amd/libpimgpu.so.
+
+This is the Python face of the C-ABI used by tests/, bench.py and __graft_entry__.py; a C host
+would include include/pimgpu.h (or the Pim-shaped wrappers in pim_amd/host/pim_host.h) instead.
+The library is hand-written HIP for gfx950; loading fails loudly when it is missing -- there is no
+CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+C = ctypes
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpimgpu.so")
+
+PIMGPU_OK = 0
+MATFLAG_EMISSIVE = 1 << 0
+MATFLAG_SKY = 1 << 1
+MATFLAG_REFRACTIVE = 1 << 5
+HIT_NOTHING, HIT_BACKFACE, HIT_TRIANGLE = 0, 1, 2
+TEX_RGBA8, TEX_XY16 = 0, 1
+RCP_EPSILON = 8388608.0
+
+
+class PimMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_int32), ("rome", C.c_int32), ("normal", C.c_int32), ("flags", C.c_uint32),
+                ("meanFreePath", C.c_float * 4), ("ior", C.c_float), ("bumpiness", C.c_float), ("_pad", C.c_float * 2)]
+
+
+class PimTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("format", C.c_int32), ("_pad", C.c_int32),
+                ("texels", C.c_void_p)]
+
+
+class PimMediaDesc(C.Structure):
+    _fields_ = [("constantColor", C.c_float * 4), ("noiseColor", C.c_float * 4), ("constantMfp", C.c_float),
+                ("noiseMfp", C.c_float), ("absorption", C.c_float), ("noiseOctaves", C.c_int32),
+                ("noiseGain", C.c_float), ("noiseLacunarity", C.c_float), ("noiseFreq", C.c_float),
+                ("noiseScale", C.c_float), ("noiseHeight", C.c_float), ("phaseDirA", C.c_float),
+                ("phaseDirB", C.c_float), ("phaseBlend", C.c_float)]
+
+
+class PimSceneDesc(C.Structure):
+    _fields_ = [("vertCount", C.c_int32), ("matCount", C.c_int32), ("texCount", C.c_int32), ("skySize", C.c_int32),
+                ("positions", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p), ("matIds", C.c_void_p),
+                ("materials", C.c_void_p), ("textures", C.c_void_p), ("skyFaces", C.c_void_p * 6),
+                ("brdfLut", C.c_void_p), ("brdfLutSize", C.c_int32), ("emissiveAttempts", C.c_int32),
+                ("metersPerCell", C.c_float), ("seed", C.c_uint32), ("media", PimMediaDesc)]
+
+
+class PimSceneInfo(C.Structure):
+    _fields_ = [("vertCount", C.c_int32), ("triCount", C.c_int32), ("matCount", C.c_int32), ("emissiveCount", C.c_int32),
+                ("gridSize", C.c_int32 * 3), ("gridLen", C.c_int32), ("activeCells", C.c_int32),
+                ("bvhNodeCount", C.c_int32), ("bvhMaxDepth", C.c_int32), ("boundsLo", C.c_float * 3),
+                ("boundsHi", C.c_float * 3), ("bvhBuildMs", C.c_float), ("sceneSetupMs", C.c_float)]
+
+
+class PimCamera(C.Structure):
+    _fields_ = [("position", C.c_float * 4), ("rotation", C.c_float * 4), ("zNear", C.c_float), ("zFar", C.c_float),
+                ("fovy", C.c_float), ("_pad", C.c_float)]
+
+
+class PimDofInfo(C.Structure):
+    _fields_ = [("aperture", C.c_float), ("focalLength", C.c_float), ("bladeCount", C.c_int32), ("bladeRot", C.c_float),
+                ("focalPlaneCurvature", C.c_float), ("autoFocusSpeed", C.c_float), ("autoFocus", C.c_int32)]
+
+
+class PimTraceParams(C.Structure):
+    _fields_ = [("sampleWeight", C.c_float), ("frameDt", C.c_float), ("sampleIndex", C.c_uint32), ("seed", C.c_uint32),
+                ("maxBounces", C.c_int32), ("updateDists", C.c_int32)]
+
+
+class PimTraceStats(C.Structure):
+    _fields_ = [("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("otherRays", C.c_uint64),
+                ("paths", C.c_uint64), ("bounces", C.c_int32), ("traceMs", C.c_float), ("totalMs", C.c_float)]
+
+
+class PimLightmapPage(C.Structure):
+    _fields_ = [("block", C.c_void_p)]
+
+
+RAYHIT_DTYPE = np.dtype([("wuvt", np.float32, 4), ("normal", np.float32, 4), ("type", np.int32), ("iVert", np.int32),
+                         ("flags", np.uint32), ("_pad", np.int32)])
+RESULT_DTYPE = np.dtype([("color", np.float32, 3), ("albedo", np.float32, 3), ("normal", np.float32, 3)])
+RAWHIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
+assert RAYHIT_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 36 and C.sizeof(PimMaterial) == 48
+
+# every symbol include/pimgpu.h declares (tests check that the built library exports all of them)
+EXPORTS = [
+    "pimgpu_init", "pimgpu_shutdown", "pimgpu_last_error",
+    "pimgpu_scene_create", "pimgpu_scene_destroy", "pimgpu_scene_rebuild_bvh", "pimgpu_scene_update_dists",
+    "pimgpu_scene_info", "pimgpu_scene_download_lights",
+    "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
+    "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
+    "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
+    "pimgpu_lightmap_bake", "pimgpu_stream",
+]
+
+_LIB = None
+
+
+class PimGpuError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen pim_amd/libpimgpu.so (built by __graft_entry__.build() / pim_amd/csrc/Makefile)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise PimGpuError(f"{LIB_PATH} is missing: build it with `make -C pim_amd/csrc` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.pimgpu_last_error.restype = C.c_char_p
+        lib.pimgpu_stream.restype = C.c_void_p
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != PIMGPU_OK:
+        msg = load_library().pimgpu_last_error().decode(errors="replace")
+        raise PimGpuError(f"{what} failed with status {rc}: {msg}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Scene:
+    """PtScene_New .. PtScene_Del (rendering/path_tracer.h:70-74) on the GPU."""
+
+    def __init__(self, desc):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        check(self.lib.pimgpu_scene_create(C.byref(desc), C.byref(self.handle)), "pimgpu_scene_create")
+        self.vertCount = desc.vertCount
+
+    def close(self):
+        if self.handle:
+            self.lib.pimgpu_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        out = PimSceneInfo()
+        check(self.lib.pimgpu_scene_info(self.handle, C.byref(out)), "pimgpu_scene_info")
+        return out
+
+    def rebuild_bvh(self):
+        check(self.lib.pimgpu_scene_rebuild_bvh(self.handle), "pimgpu_scene_rebuild_bvh")
+
+    def update_dists(self):
+        check(self.lib.pimgpu_scene_update_dists(self.handle), "pimgpu_scene_update_dists")
+
+    def download_lights(self):
+        info = self.info()
+        E, L, V = info.emissiveCount, info.gridLen, info.vertCount
+        out = dict(vertToEmit=np.zeros(V, np.int32), emitToVert=np.zeros(E, np.int32), cellLength=np.zeros(L, np.int32),
+                   pdf=np.zeros(L * E, np.float32), cdf=np.zeros(L * (E + 1), np.float32), live=np.zeros(L * E, np.uint32))
+        check(self.lib.pimgpu_scene_download_lights(self.handle, _ptr(out["vertToEmit"]), _ptr(out["emitToVert"]),
+              _ptr(out["cellLength"]), _ptr(out["pdf"]), _ptr(out["cdf"]), _ptr(out["live"])), "pimgpu_scene_download_lights")
+        return out
+
+    def intersect(self, ro, rd, tNear=None, tFar=None):
+        """batched Pt_Intersect: ro/rd (n,4) float32 -> structured array of PtRayHit"""
+        ro, rd = f32(ro), f32(rd)
+        n = ro.shape[0]
+        tn = f32(tNear) if tNear is not None else np.zeros(n, np.float32)
+        tf = f32(tFar) if tFar is not None else np.full(n, RCP_EPSILON, np.float32)
+        out = np.zeros(n, RAYHIT_DTYPE)
+        check(self.lib.pimgpu_intersect(self.handle, _ptr(ro), _ptr(rd), _ptr(tn), _ptr(tf), C.c_int32(n), _ptr(out)), "pimgpu_intersect")
+        return out
+
+    def trace_rays(self, ro, rd, sampleIndex=0, seed=0, maxBounces=0):
+        ro, rd = f32(ro), f32(rd)
+        n = ro.shape[0]
+        out = np.zeros(n, RESULT_DTYPE)
+        check(self.lib.pimgpu_trace_rays(self.handle, _ptr(ro), _ptr(rd), C.c_int32(n), C.c_uint32(sampleIndex), C.c_uint32(seed),
+              C.c_int32(maxBounces), _ptr(out)), "pimgpu_trace_rays")
+        return out
+
+    def raygen(self, origin, count, sampleIndex=0, seed=0, maxBounces=0):
+        origin = f32(origin)
+        colors = np.zeros((count, 4), np.float32)
+        directions = np.zeros((count, 4), np.float32)
+        check(self.lib.pimgpu_raygen(self.handle, _ptr(origin), C.c_int32(count), C.c_uint32(sampleIndex), C.c_uint32(seed),
+              C.c_int32(maxBounces), _ptr(colors), _ptr(directions)), "pimgpu_raygen")
+        return colors, directions
+
+    def lightmap_bake(self, pages, lmSize, texelsPerMeter, timeSlice, spp, passIndex=0, seed=0, maxBounces=0,
+                      texelBegin=0, texelEnd=-1):
+        """pages: list of float32 arrays of lmSize*lmSize*27 floats each (the reference's page layout), updated in place"""
+        arr = (PimLightmapPage * len(pages))()
+        for i, p in enumerate(pages):
+            assert p.dtype == np.float32 and p.flags["C_CONTIGUOUS"] and p.size == lmSize * lmSize * 27
+            arr[i].block = p.ctypes.data
+        check(self.lib.pimgpu_lightmap_bake(self.handle, arr, C.c_int32(len(pages)), C.c_int32(lmSize), C.c_float(texelsPerMeter),
+              C.c_float(timeSlice), C.c_int32(spp), C.c_uint32(passIndex), C.c_uint32(seed), C.c_int32(maxBounces),
+              C.c_int64(texelBegin), C.c_int64(texelEnd)), "pimgpu_lightmap_bake")
+
+
+class Trace:
+    """PtTrace_New .. PtTrace_Del + Pt_Trace (rendering/path_tracer.h:76-77,101)."""
+
+    def __init__(self, width, height):
+        self.lib = load_library()
+        self.width, self.height = width, height
+        self.handle = C.c_void_p()
+        check(self.lib.pimgpu_trace_create(C.c_int32(width), C.c_int32(height), C.byref(self.handle)), "pimgpu_trace_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.pimgpu_trace_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(self.lib.pimgpu_trace_clear(self.handle), "pimgpu_trace_clear")
+
+    def trace(self, scene, camera, dof, params):
+        check(self.lib.pimgpu_trace_image(scene.handle, self.handle, C.byref(camera), C.byref(dof), C.byref(params)), "pimgpu_trace_image")
+
+    def download(self):
+        n = self.width * self.height
+        color, albedo, normal = (np.zeros((n, 3), np.float32) for _ in range(3))
+        check(self.lib.pimgpu_trace_download(self.handle, _ptr(color), _ptr(albedo), _ptr(normal)), "pimgpu_trace_download")
+        return color, albedo, normal
+
+    def buffers(self):
+        c, a, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.lib.pimgpu_trace_buffers(self.handle, C.byref(c), C.byref(a), C.byref(n)), "pimgpu_trace_buffers")
+        return c.value, a.value, n.value
+
+    def stddev(self):
+        m, s = C.c_float(), C.c_float()
+        check(self.lib.pimgpu_trace_stddev(self.handle, C.byref(m), C.byref(s)), "pimgpu_trace_stddev")
+        return m.value, s.value
+
+    def stats(self):
+        out = PimTraceStats()
+        check(self.lib.pimgpu_trace_stats(self.handle, C.byref(out)), "pimgpu_trace_stats")
+        return out
+
+
+def init(device=0):
+    check(load_library().pimgpu_init(C.c_int(device)), "pimgpu_init")
+
+
+def shutdown():
+    load_library().pimgpu_shutdown()

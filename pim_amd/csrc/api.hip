@@ -1,0 +1,399 @@
+/*
+ * api.hip -- the C-ABI of libpimgpu.so (include/pimgpu.h): library state, scene upload and
+ * set-up, batched ray queries.  Image, ray-batch and lightmap entry points are in integrate.hip.
+ */
+#include "pt_host.h"
+#include "pt_api.h"
+#include "traverse.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+namespace pt {
+
+static thread_local char g_error[512] = "";
+Library g_lib;
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int check_ready()
+{
+    if (!g_lib.initialised) { set_error("pimgpu_init has not been called"); return PIMGPU_E_STATE; }
+    return PIMGPU_OK;
+}
+
+template <class T>
+static int upload(T** dst, const void* src, size_t count)
+{
+    *dst = nullptr;
+    const size_t bytes = sizeof(T) * (count ? count : 1);
+    if (hipMalloc((void**)dst, bytes) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); return PIMGPU_E_NOMEM; }
+    if (count && src) PT_HIP(hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice));
+    else PT_HIP(hipMemset(*dst, 0, bytes));
+    return PIMGPU_OK;
+}
+
+/* media_desc_update, path_tracer.c:1963-1987 */
+static void media_from_desc(DMedia* m, const PimMediaDesc* d)
+{
+    m->constantColor = f4_v(d->constantColor[0], d->constantColor[1], d->constantColor[2], d->constantColor[3]);
+    m->noiseColor = f4_v(d->noiseColor[0], d->noiseColor[1], d->noiseColor[2], d->noiseColor[3]);
+    m->constantMfp = d->constantMfp; m->noiseMfp = d->noiseMfp; m->absorption = d->absorption;
+    m->noiseOctaves = d->noiseOctaves; m->noiseGain = d->noiseGain; m->noiseLacunarity = d->noiseLacunarity;
+    m->noiseFreq = d->noiseFreq; m->noiseScale = d->noiseScale; m->noiseHeight = d->noiseHeight;
+    m->phaseDirA = d->phaseDirA; m->phaseDirB = d->phaseDirB; m->phaseBlend = d->phaseBlend;
+    const v4 constantMfp = f4_lerpsv(m->constantMfp * 0.5f, m->constantMfp * 2.0f, m->constantColor);
+    const v4 noiseMfp = f4_lerpsv(m->noiseMfp * 0.5f, m->noiseMfp * 2.0f, m->noiseColor);
+    m->constantMu = f4_rcp(constantMfp);
+    m->noiseMu = f4_rcp(noiseMfp);
+    m->phaseDirA = f1_clamp(m->phaseDirA, -0.99f, 0.99f);
+    m->phaseDirB = f1_clamp(m->phaseDirB, -0.99f, 0.99f);
+    m->phaseBlend = f1_sat(m->phaseBlend);
+    float sum = 0.0f, amplitude = 1.0f;
+    for (int32_t i = 0; i < m->noiseOctaves; ++i) { sum += amplitude; amplitude *= m->noiseGain; }
+    m->noiseRange = sum * m->noiseScale * 1.5f;
+    /* CalcMajorant, path_tracer.c:2183-2196 */
+    const float a = 1.0f + m->absorption;
+    const v4 maj = f4_muls(f4_add(f4_muls(m->constantMu, a), f4_muls(m->noiseMu, a)), 2.0f);
+    m->rcpMajorant = 1.0f / f4_hmax3(maj);
+}
+
+static void scene_free(PimScene* s)
+{
+    if (!s) return;
+    hipFree(s->positions); hipFree(s->normals); hipFree(s->uvs); hipFree(s->matIds);
+    hipFree(s->vertToEmit); hipFree(s->emitToVert); hipFree(s->materials); hipFree(s->textures);
+    for (void* p : s->texels) hipFree(p);
+    for (int f = 0; f < 6; ++f) hipFree(s->sky[f]);
+    hipFree(s->lut);
+    hipFree(s->cellLength); hipFree(s->pdf); hipFree(s->cdf); hipFree(s->live); hipFree(s->cellSum); hipFree(s->cellIntegral);
+    s->bvh.release();
+    delete s;
+}
+
+static int check_status_word(const char* what)
+{
+    uint32_t st = 0;
+    PT_HIP(hipMemcpy(&st, g_lib.trace.status, 4, hipMemcpyDeviceToHost));
+    if (st & 1u)
+    {
+        PT_HIP(hipMemset(g_lib.trace.status, 0, 4));
+        set_error("%s: traversal stack overflow (tree deeper than %d entries)", what, PT_STACK_MAX);
+        return PIMGPU_E_LIMIT;
+    }
+    return PIMGPU_OK;
+}
+
+static int scene_build_bvh(PimScene* s)
+{
+    hipEvent_t e0, e1;
+    PT_HIP(hipEventCreate(&e0)); PT_HIP(hipEventCreate(&e1));
+    PT_HIP(hipEventRecord(e0, g_lib.stream));
+    int rc = bvh_build(&s->bvh, s->positions, s->d.triCount, g_lib.stream);
+    PT_HIP(hipEventRecord(e1, g_lib.stream));
+    PT_HIP(hipEventSynchronize(e1));
+    hipEventElapsedTime(&s->bvhBuildMs, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (rc) { if (rc == PIMGPU_E_NOMEM) set_error("out of device memory building the BVH"); return rc; }
+    s->d.bvh = s->bvh.view();
+    if (s->bvh.maxDepthDev) PT_HIP(hipMemcpy(&s->bvhDepth, s->bvh.maxDepthDev, 4, hipMemcpyDeviceToHost));
+    return PIMGPU_OK;
+}
+
+} /* namespace pt */
+
+using namespace pt;
+
+extern "C" {
+
+int pimgpu_init(int device)
+{
+    if (g_lib.initialised) return PIMGPU_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return PIMGPU_E_DEVICE; }
+    if (device < 0 || device >= count) { set_error("device %d out of range (have %d)", device, count); return PIMGPU_E_INVALID; }
+    PT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PT_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        set_error("device %d is %s; libpimgpu is built for gfx950 only", device, prop.gcnArchName);
+        return PIMGPU_E_DEVICE;
+    }
+    PT_HIP(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
+    g_lib.device = device;
+    g_lib.cuCount = prop.multiProcessorCount;
+    int rc = g_lib.trace.ensure();
+    if (rc) return rc;
+    g_lib.initialised = true;
+    return PIMGPU_OK;
+}
+
+int pimgpu_shutdown(void)
+{
+    if (!g_lib.initialised) return PIMGPU_OK;
+    hipStreamSynchronize(g_lib.stream);
+    g_lib.work.release();
+    g_lib.trace.release();
+    hipStreamDestroy(g_lib.stream);
+    g_lib.stream = nullptr;
+    g_lib.initialised = false;
+    return PIMGPU_OK;
+}
+
+const char* pimgpu_last_error(void) { return g_error; }
+
+void* pimgpu_stream(void) { return (void*)g_lib.stream; }
+
+int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
+{
+    if (out) *out = nullptr;
+    int rc = check_ready(); if (rc) return rc;
+    if (!d || !out) { set_error("scene_create: NULL argument"); return PIMGPU_E_INVALID; }
+    if (d->vertCount < 0 || (d->vertCount % 3) != 0) { set_error("scene_create: vertCount %d is not a multiple of 3", d->vertCount); return PIMGPU_E_INVALID; }
+    if (d->vertCount / 3 >= (1 << 28)) { set_error("scene_create: more than 2^28 triangles"); return PIMGPU_E_LIMIT; }
+    if (d->vertCount > 0 && (!d->positions || !d->normals || !d->uvs || !d->matIds || !d->materials || d->matCount <= 0))
+    { set_error("scene_create: missing vertex or material arrays"); return PIMGPU_E_INVALID; }
+    if (d->texCount > 0 && !d->textures) { set_error("scene_create: texCount > 0 but textures == NULL"); return PIMGPU_E_INVALID; }
+    if (!d->brdfLut || d->brdfLutSize <= 0) { set_error("scene_create: the BRDF LUT (lighting.h g_BrdfLut) is required"); return PIMGPU_E_INVALID; }
+    for (int32_t i = 0; i < d->vertCount; ++i)
+    {
+        if (d->matIds[i] < 0 || d->matIds[i] >= d->matCount) { set_error("scene_create: matIds[%d] = %d out of range", i, d->matIds[i]); return PIMGPU_E_INVALID; }
+    }
+    for (int32_t i = 0; i < d->matCount; ++i)
+    {
+        const PimMaterial& m = d->materials[i];
+        if (m.albedo >= d->texCount || m.rome >= d->texCount || m.normal >= d->texCount) { set_error("scene_create: material %d names a texture out of range", i); return PIMGPU_E_INVALID; }
+    }
+    for (int32_t i = 0; i < d->texCount; ++i)
+    {
+        if (d->textures[i].width <= 0 || d->textures[i].height <= 0 || !d->textures[i].texels) { set_error("scene_create: texture %d is empty", i); return PIMGPU_E_INVALID; }
+    }
+
+    PimScene* s = new PimScene();
+    auto fail = [&](int code) { scene_free(s); return code; };
+    const size_t V = (size_t)d->vertCount;
+    s->d.vertCount = d->vertCount; s->d.triCount = d->vertCount / 3; s->d.matCount = d->matCount; s->d.texCount = d->texCount;
+    s->seed = d->seed;
+    s->metersPerCell = d->metersPerCell > 0.0f ? d->metersPerCell : 1.5f;
+    if ((rc = upload(&s->positions, d->positions, V))) return fail(rc);
+    if ((rc = upload(&s->normals, d->normals, V))) return fail(rc);
+    if ((rc = upload(&s->uvs, d->uvs, V))) return fail(rc);
+    if ((rc = upload(&s->matIds, d->matIds, V))) return fail(rc);
+    if ((rc = upload(&s->materials, d->materials, (size_t)d->matCount))) return fail(rc);
+    {
+        std::vector<DTexture> tex((size_t)d->texCount);
+        for (int32_t i = 0; i < d->texCount; ++i)
+        {
+            uint32_t* texels = nullptr;
+            if ((rc = upload(&texels, d->textures[i].texels, (size_t)d->textures[i].width * d->textures[i].height))) return fail(rc);
+            s->texels.push_back(texels);
+            tex[i].width = d->textures[i].width; tex[i].height = d->textures[i].height; tex[i].format = d->textures[i].format; tex[i]._pad = 0;
+            tex[i].texels = texels;
+        }
+        if ((rc = upload(&s->textures, tex.data(), tex.size()))) return fail(rc);
+    }
+    s->d.skySize = d->skySize;
+    if (d->skySize > 0)
+    {
+        for (int f = 0; f < 6; ++f)
+        {
+            if (!d->skyFaces[f]) { set_error("scene_create: sky face %d is NULL", f); return fail(PIMGPU_E_INVALID); }
+            if ((rc = upload(&s->sky[f], d->skyFaces[f], (size_t)d->skySize * d->skySize))) return fail(rc);
+            s->d.sky[f] = s->sky[f];
+        }
+    }
+    s->d.lutSize = d->brdfLutSize;
+    if ((rc = upload(&s->lut, d->brdfLut, (size_t)d->brdfLutSize * d->brdfLutSize))) return fail(rc);
+    s->d.lut = s->lut;
+    media_from_desc(&s->d.media, &d->media);
+    s->d.positions = s->positions; s->d.normals = s->normals; s->d.uvs = s->uvs; s->d.matIds = s->matIds;
+    s->d.materials = s->materials; s->d.textures = s->textures;
+
+    hipEvent_t e0, e1;
+    PT_HIP(hipEventCreate(&e0)); PT_HIP(hipEventCreate(&e1));
+    float msEmit = 0.0f, msGrid = 0.0f;
+
+    /* PtScene_Init order, path_tracer.c:1039-1049: SetupEmissives, RtcNewScene, SetupLightGrid */
+    const int32_t triCount = s->d.triCount;
+    {
+        float* pdfsDev = nullptr;
+        if ((rc = upload(&pdfsDev, nullptr, (size_t)triCount))) return fail(rc);
+        PT_HIP(hipEventRecord(e0, g_lib.stream));
+        rc = setup_emission_pdfs(s->d, d->emissiveAttempts > 0 ? d->emissiveAttempts : 1000, s->seed, pdfsDev, g_lib.stream);
+        PT_HIP(hipEventRecord(e1, g_lib.stream));
+        if (rc) { hipFree(pdfsDev); return fail(rc); }
+        std::vector<float> pdfs((size_t)triCount);
+        PT_HIP(hipMemcpyAsync(pdfs.data(), pdfsDev, sizeof(float) * (size_t)triCount, hipMemcpyDeviceToHost, g_lib.stream));
+        PT_HIP(hipStreamSynchronize(g_lib.stream));
+        hipEventElapsedTime(&msEmit, e0, e1);
+        hipFree(pdfsDev);
+        /* ordered compaction of the emissive triangles, path_tracer.c:861-880 */
+        std::vector<int32_t> vertToEmit(V), emitToVert;
+        for (int32_t iTri = 0; iTri < triCount; ++iTri)
+        {
+            const int32_t iVert = iTri * 3;
+            int32_t e = -1;
+            if (pdfs[(size_t)iTri] > 0.01f) { e = (int32_t)emitToVert.size(); emitToVert.push_back(iVert); }
+            vertToEmit[(size_t)iVert + 0] = vertToEmit[(size_t)iVert + 1] = vertToEmit[(size_t)iVert + 2] = e;
+        }
+        s->d.emissiveCount = (int32_t)emitToVert.size();
+        if ((rc = upload(&s->vertToEmit, vertToEmit.data(), V))) return fail(rc);
+        if ((rc = upload(&s->emitToVert, emitToVert.data(), emitToVert.size()))) return fail(rc);
+        s->d.vertToEmit = s->vertToEmit; s->d.emitToVert = s->emitToVert;
+    }
+    if ((rc = scene_build_bvh(s))) return fail(rc);
+    {
+        /* SetupLightGrid, path_tracer.c:992-1009; box_from_pts math/box.h:53-68 */
+        if (V > 0)
+        {
+            v4 lo = f4_s((float)(1 << 23)), hi = f4_s(-(float)(1 << 23));
+            const v4* pos = (const v4*)d->positions;
+            for (size_t i = 0; i < V; ++i) { lo = f4_min(lo, pos[i]); hi = f4_max(hi, pos[i]); }
+            DGrid g;
+            const float cellsPerMeter = 1.0f / s->metersPerCell;
+            const v4 sizef = f4_ceil(f4_muls(f4_sub(hi, lo), cellsPerMeter));
+            g.lo = lo; g.hi = hi; g.sx = (int32_t)sizef.x; g.sy = (int32_t)sizef.y; g.sz = (int32_t)sizef.z; g.cellsPerMeter = cellsPerMeter;
+            const int64_t len = (int64_t)g.sx * g.sy * g.sz;
+            if (len <= 0 || len > (1ll << 30)) { set_error("scene_create: light grid of %lld cells", (long long)len); return fail(PIMGPU_E_LIMIT); }
+            s->d.grid = g; s->d.gridLen = (int32_t)len;
+        }
+        const size_t len = (size_t)s->d.gridLen, E = (size_t)s->d.emissiveCount;
+        if ((rc = upload(&s->cellLength, nullptr, len))) return fail(rc);
+        if ((rc = upload(&s->pdf, nullptr, len * E))) return fail(rc);
+        if ((rc = upload(&s->cdf, nullptr, len * (E + 1)))) return fail(rc);
+        if ((rc = upload(&s->live, nullptr, len * E))) return fail(rc);
+        if ((rc = upload(&s->cellSum, nullptr, len))) return fail(rc);
+        if ((rc = upload(&s->cellIntegral, nullptr, len))) return fail(rc);
+        s->d.cellLength = s->cellLength; s->d.pdf = s->pdf; s->d.cdf = s->cdf; s->d.live = s->live;
+        s->d.cellSum = s->cellSum; s->d.cellIntegral = s->cellIntegral;
+        PT_HIP(hipEventRecord(e0, g_lib.stream));
+        rc = setup_light_grid(s->d, s->metersPerCell, s->seed, s->cellLength, g_lib.trace.status, g_lib.stream);
+        PT_HIP(hipEventRecord(e1, g_lib.stream));
+        if (rc) return fail(rc);
+        PT_HIP(hipStreamSynchronize(g_lib.stream));
+        hipEventElapsedTime(&msGrid, e0, e1);
+        if ((rc = check_status_word("scene_create"))) return fail(rc);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    s->setupMs = msEmit + msGrid;
+    *out = s;
+    return PIMGPU_OK;
+}
+
+int pimgpu_scene_destroy(PimScene* scene)
+{
+    if (!scene) return PIMGPU_OK;
+    if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
+    scene_free(scene);
+    return PIMGPU_OK;
+}
+
+int pimgpu_scene_rebuild_bvh(PimScene* scene)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene) { set_error("scene_rebuild_bvh: NULL scene"); return PIMGPU_E_INVALID; }
+    return scene_build_bvh(scene);
+}
+
+int pimgpu_scene_update_dists(PimScene* scene)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene) { set_error("scene_update_dists: NULL scene"); return PIMGPU_E_INVALID; }
+    if ((rc = update_dists(scene->d, g_lib.stream))) return rc;
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
+int pimgpu_scene_info(const PimScene* s, PimSceneInfo* out)
+{
+    if (!s || !out) { set_error("scene_info: NULL argument"); return PIMGPU_E_INVALID; }
+    memset(out, 0, sizeof(*out));
+    out->vertCount = s->d.vertCount; out->triCount = s->d.triCount; out->matCount = s->d.matCount;
+    out->emissiveCount = s->d.emissiveCount;
+    out->gridSize[0] = s->d.grid.sx; out->gridSize[1] = s->d.grid.sy; out->gridSize[2] = s->d.grid.sz;
+    out->gridLen = s->d.gridLen;
+    if (s->d.gridLen > 0)
+    {
+        std::vector<int32_t> len((size_t)s->d.gridLen);
+        PT_HIP(hipMemcpy(len.data(), s->cellLength, sizeof(int32_t) * len.size(), hipMemcpyDeviceToHost));
+        for (int32_t v : len) out->activeCells += v ? 1 : 0;
+    }
+    out->bvhNodeCount = s->bvh.nodeCount; out->bvhMaxDepth = s->bvhDepth;
+    out->boundsLo[0] = s->d.grid.lo.x; out->boundsLo[1] = s->d.grid.lo.y; out->boundsLo[2] = s->d.grid.lo.z;
+    out->boundsHi[0] = s->d.grid.hi.x; out->boundsHi[1] = s->d.grid.hi.y; out->boundsHi[2] = s->d.grid.hi.z;
+    out->bvhBuildMs = s->bvhBuildMs; out->sceneSetupMs = s->setupMs;
+    return PIMGPU_OK;
+}
+
+int pimgpu_scene_download_lights(const PimScene* s, int32_t* vertToEmit, int32_t* emitToVert, int32_t* cellLength,
+    float* pdf, float* cdf, uint32_t* live)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!s) { set_error("scene_download_lights: NULL scene"); return PIMGPU_E_INVALID; }
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    const size_t E = (size_t)s->d.emissiveCount, L = (size_t)s->d.gridLen, V = (size_t)s->d.vertCount;
+    if (vertToEmit && V) PT_HIP(hipMemcpy(vertToEmit, s->vertToEmit, 4 * V, hipMemcpyDeviceToHost));
+    if (emitToVert && E) PT_HIP(hipMemcpy(emitToVert, s->emitToVert, 4 * E, hipMemcpyDeviceToHost));
+    if (cellLength && L) PT_HIP(hipMemcpy(cellLength, s->cellLength, 4 * L, hipMemcpyDeviceToHost));
+    if (pdf && L * E) PT_HIP(hipMemcpy(pdf, s->pdf, 4 * L * E, hipMemcpyDeviceToHost));
+    if (cdf && L) PT_HIP(hipMemcpy(cdf, s->cdf, 4 * L * (E + 1), hipMemcpyDeviceToHost));
+    if (live && L * E) PT_HIP(hipMemcpy(live, s->live, 4 * L * E, hipMemcpyDeviceToHost));
+    return PIMGPU_OK;
+}
+
+/* ---- rays ---------------------------------------------------------------- */
+
+int pimgpu_intersect_dev(const PimScene* scene, const void* roDev, const void* rdDev, const void* tNearDev, const void* tFarDev,
+    int32_t n, void* hitsDev)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || n < 0 || (n > 0 && (!roDev || !rdDev || !hitsDev))) { set_error("intersect_dev: bad argument"); return PIMGPU_E_INVALID; }
+    if (n == 0) return PIMGPU_OK;
+    if ((rc = g_lib.work.ensure_rays(n))) return rc;
+    /* pack (ro.xyz, tNear) / (rd.xyz, tFar); NULL tNear/tFar mean 0 and kRcpEpsilon */
+    if ((rc = pack_rays((const float4*)roDev, (const float4*)rdDev, (const float*)tNearDev, (const float*)tFarDev, n,
+        g_lib.work.rayO, g_lib.work.rayD, g_lib.stream))) return rc;
+    if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, g_lib.work.rayO, g_lib.work.rayD, (DHit*)hitsDev, n, nullptr, g_lib.stream))) return rc;
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return check_status_word("intersect");
+}
+
+int pimgpu_intersect_packed_dev(const PimScene* scene, const void* rayODev, const void* rayDDev, int32_t n, void* hitsDev)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || n < 0 || (n > 0 && (!rayODev || !rayDDev || !hitsDev))) { set_error("intersect_packed_dev: bad argument"); return PIMGPU_E_INVALID; }
+    if (n == 0) return PIMGPU_OK;
+    if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, (const float4*)rayODev, (const float4*)rayDDev, (DHit*)hitsDev, n, nullptr, g_lib.stream))) return rc;
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return check_status_word("intersect");
+}
+
+int pimgpu_intersect(const PimScene* scene, const float* ro, const float* rd, const float* tNear, const float* tFar,
+    int32_t n, PimRayHit* out)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || n < 0 || (n > 0 && (!ro || !rd || !out))) { set_error("intersect: bad argument"); return PIMGPU_E_INVALID; }
+    if (n == 0) return PIMGPU_OK;
+    float4 *roDev = nullptr, *rdDev = nullptr; float *tnDev = nullptr, *tfDev = nullptr; DHit* hitsDev = nullptr; PimRayHit* outDev = nullptr;
+    auto cleanup = [&]() { hipFree(roDev); hipFree(rdDev); hipFree(tnDev); hipFree(tfDev); hipFree(hitsDev); hipFree(outDev); };
+    if ((rc = upload(&roDev, ro, (size_t)n)) || (rc = upload(&rdDev, rd, (size_t)n)) ||
+        (tNear && (rc = upload(&tnDev, tNear, (size_t)n))) || (tFar && (rc = upload(&tfDev, tFar, (size_t)n))) ||
+        (rc = upload(&hitsDev, nullptr, (size_t)n)) || (rc = upload(&outDev, nullptr, (size_t)n)))
+    { cleanup(); return rc; }
+    rc = pimgpu_intersect_dev(scene, roDev, rdDev, tnDev, tfDev, n, hitsDev);
+    if (!rc) rc = make_rayhits(scene->d, rdDev, hitsDev, outDev, n, g_lib.stream);
+    if (!rc && hipMemcpyAsync(out, outDev, sizeof(PimRayHit) * (size_t)n, hipMemcpyDeviceToHost, g_lib.stream) != hipSuccess) { set_error("intersect: copy back failed"); rc = PIMGPU_E_DEVICE; }
+    hipStreamSynchronize(g_lib.stream);
+    cleanup();
+    return rc;
+}
+
+} /* extern "C" */

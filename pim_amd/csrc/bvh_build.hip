@@ -1,0 +1,495 @@
+/*
+ * bvh_build.hip -- GPU BVH build; replaces rtcCommitScene (rendering/path_tracer.c:618-690,
+ * RTC_GEOMETRY_TYPE_TRIANGLE, identity index buffer, primID*3 == iVert).
+ *
+ * Pipeline, all on one stream, no host round trip:
+ *   tri_bounds  : per-triangle padded AABB + scene centroid bounds (wave reduce + ordered-uint atomics)
+ *   morton      : 63-bit Morton code of the centroid (21 bits per axis)
+ *   radix sort  : hand-written 8-bit LSD radix sort of (u64 key, u32 triangle) pairs,
+ *                 wave64 ballot-match ranking (stable), 3 kernels per pass
+ *   karras      : LBVH topology from the sorted codes (Karras 2012), one lane per inner node
+ *   refit       : bottom-up AABB union, second arriver at a node proceeds (agent-scope acq_rel atomic)
+ *   collapse    : subtrees with <= PT_LEAF_MAX triangles become one leaf; every other level of the
+ *                 binary tree is folded away -> 4-wide nodes of 128 B (layout: pt_device.h)
+ *   emit_tris   : triangles copied in leaf order (3 float4 each, primID in p0.w)
+ *
+ * The closest-hit contract (lowest primID among equal t, exact fp32 watertight test per lane)
+ * makes query RESULTS independent of the tree's shape; the tree only has to be conservative,
+ * which the padded triangle boxes guarantee.
+ */
+#include "pt_host.h"
+
+namespace pt {
+
+static constexpr int kSortThreads = 256;
+static constexpr int kSortRounds = 8;                      /* keys per thread */
+static constexpr int kSortTile = kSortThreads * kSortRounds;
+
+__device__ __forceinline__ uint32_t float_to_ordered(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+/* bounds[0..2] = ordered min of centroids, bounds[3..5] = ordered max */
+__global__ void k_bounds_init(uint32_t* bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_tri_bounds(const v4* __restrict__ positions, int32_t triCount,
+    float4* __restrict__ triLo, float4* __restrict__ triHi, uint32_t* __restrict__ bounds)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float c[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
+    float d[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    if (i < triCount)
+    {
+        const v4 p0 = positions[i * 3 + 0], p1 = positions[i * 3 + 1], p2 = positions[i * 3 + 2];
+        float lo[3] = { fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)) };
+        float hi[3] = { fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)) };
+        for (int a = 0; a < 3; ++a)
+        {
+            c[a] = d[a] = 0.5f * (lo[a] + hi[a]);
+            const float m = fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), 1e-3f);
+            const float pad = m * 4.0e-7f;          /* conservative against the rounding of the slab test */
+            lo[a] -= pad; hi[a] += pad;
+        }
+        triLo[i] = make_float4(lo[0], lo[1], lo[2], c[0]);
+        triHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    for (int a = 0; a < 3; ++a)
+    {
+        const float mn = wave_min(c[a]), mx = wave_max(d[a]);
+        if ((threadIdx.x & 63) == 0 && mn <= mx)
+        {
+            atomicMin(&bounds[a], float_to_ordered(mn));
+            atomicMax(&bounds[3 + a], float_to_ordered(mx));
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t expand_bits21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    int32_t triCount, const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= triCount) return;
+    const float4 lo = triLo[i], hi = triHi[i];
+    uint32_t q[3];
+    const float cc[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
+    for (int a = 0; a < 3; ++a)
+    {
+        const float mn = ordered_to_float(bounds[a]), mx = ordered_to_float(bounds[3 + a]);
+        const float ext = mx - mn;
+        float t = (ext > 0.0f) ? (cc[a] - mn) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        uint32_t v = (uint32_t)(t * 2097152.0f);
+        q[a] = v > 2097151u ? 2097151u : v;
+    }
+    keys[i] = (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2]);
+    vals[i] = (uint32_t)i;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* radix sort, 8 bits per pass.  counts layout: counts[digit * numBlocks + block]                  */
+
+__global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __restrict__ keys, int32_t n, int shift,
+    uint32_t* __restrict__ counts, int32_t numBlocks)
+{
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortRounds; ++r)
+    {
+        const int64_t i = base + r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(uint32_t)(keys[i] >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)threadIdx.x * numBlocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+/* one block per digit: exclusive scan of that digit's row of per-block counts, digit total out */
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ counts, int32_t numBlocks, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t part[256];
+    uint32_t* row = counts + (size_t)blockIdx.x * numBlocks;
+    const int32_t per = (numBlocks + 255) / 256;
+    const int32_t b0 = threadIdx.x * per, b1 = min(b0 + per, numBlocks);
+    uint32_t s = 0;
+    for (int32_t b = b0; b < b1; ++b) s += row[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; ++i) { uint32_t v = part[i]; part[i] = run; run += v; }
+        totals[blockIdx.x] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int32_t b = b0; b < b1; ++b) { uint32_t v = row[b]; row[b] = run; run += v; }
+}
+
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn,
+    uint64_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut, int32_t n, int shift,
+    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ totals, int32_t numBlocks)
+{
+    constexpr int kWaves = kSortThreads / 64;
+    __shared__ uint32_t waveCnt[kWaves][256];
+    __shared__ uint32_t digitBase[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < kWaves; ++w) waveCnt[w][threadIdx.x] = 0;
+    /* global base of each digit = exclusive scan of the 256 digit totals */
+    digitBase[threadIdx.x] = totals[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; ++i) { uint32_t v = digitBase[i]; digitBase[i] = run; run += v; }
+    }
+    __syncthreads();
+
+    /* each wave owns a contiguous run of kSortRounds*64 keys: stable rank = (wave, round, lane) order */
+    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * (kSortRounds * 64);
+    uint64_t key[kSortRounds]; uint32_t val[kSortRounds]; uint32_t rank[kSortRounds];
+    const uint64_t ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < kSortRounds; ++r)
+    {
+        const int64_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keysIn[i] : ~0ull;
+        val[r] = valid ? valsIn[i] : 0u;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
+        uint64_t match = __ballot(valid);
+        for (int b = 0; b < 8; ++b)
+        {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            match &= bit ? m : ~m;
+        }
+        const uint32_t prev = waveCnt[wave][d];
+        rank[r] = prev + (uint32_t)__popcll(match & ltMask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (match & ltMask) == 0) waveCnt[wave][d] = prev + (uint32_t)__popcll(match);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    /* exclusive prefix over the waves, per digit (thread = digit) */
+    {
+        uint32_t run = digitBase[threadIdx.x] + counts[(size_t)threadIdx.x * numBlocks + blockIdx.x];
+        for (int w = 0; w < kWaves; ++w) { uint32_t v = waveCnt[w][threadIdx.x]; waveCnt[w][threadIdx.x] = run; run += v; }
+    }
+    __syncthreads();
+    for (int r = 0; r < kSortRounds; ++r)
+    {
+        const int64_t i = base + r * 64 + lane;
+        if (i < n)
+        {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
+            const uint32_t dst = waveCnt[wave][d] + rank[r];
+            keysOut[dst] = key[r];
+            valsOut[dst] = val[r];
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* LBVH topology (Karras 2012).  Node ids: inner i in [0, n-1), leaf j -> (n-1) + j.               */
+
+__device__ __forceinline__ int lbvh_delta(const uint64_t* __restrict__ keys, int32_t n, int32_t i, int32_t j)
+{
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+__global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ keys, int32_t n,
+    int32_t* __restrict__ child0, int32_t* __restrict__ child1, int32_t* __restrict__ parent,
+    int32_t* __restrict__ rangeFirst, int32_t* __restrict__ rangeLast)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int32_t lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int32_t l = 0;
+    for (int32_t t = lmax >> 1; t >= 1; t >>= 1)
+    {
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    }
+    const int32_t j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int32_t s = 0;
+    int32_t t = l;
+    do
+    {
+        t = (t + 1) >> 1;
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int32_t gamma = i + s * d + min(d, 0);
+    const int32_t first = min(i, j), last = max(i, j);
+    const int32_t c0 = (first == gamma) ? (n - 1) + gamma : gamma;
+    const int32_t c1 = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+    child0[i] = c0; child1[i] = c1;
+    parent[c0] = i; parent[c1] = i;
+    if (i == 0) parent[0] = -1;
+    rangeFirst[i] = first; rangeLast[i] = last;
+}
+
+/* bottom-up refit: nodeLo/nodeHi for inner nodes; leaves read the (padded) triangle boxes */
+__global__ __launch_bounds__(256) void k_refit(int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    const int32_t* __restrict__ child0, const int32_t* __restrict__ child1, const int32_t* __restrict__ parent,
+    float4* nodeLo, float4* nodeHi, uint32_t* flags)
+{
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int32_t node = parent[(n - 1) + j];
+    while (node >= 0)
+    {
+        /* the first arriver stops; the second sees both children complete (acq_rel at agent scope:
+         * the sibling's box was written by another workgroup, possibly on another XCD) */
+        const uint32_t old = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0u) return;
+        const int32_t c0 = child0[node], c1 = child1[node];
+        float4 lo0, hi0, lo1, hi1;
+        if (c0 >= n - 1) { const uint32_t t = vals[c0 - (n - 1)]; lo0 = triLo[t]; hi0 = triHi[t]; }
+        else { lo0 = nodeLo[c0]; hi0 = nodeHi[c0]; }
+        if (c1 >= n - 1) { const uint32_t t = vals[c1 - (n - 1)]; lo1 = triLo[t]; hi1 = triHi[t]; }
+        else { lo1 = nodeLo[c1]; hi1 = nodeHi[c1]; }
+        nodeLo[node] = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+        nodeHi[node] = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
+        node = parent[node];
+    }
+}
+
+/* depth parity of every inner node (root = even).  Even nodes that are not collapsed into a leaf
+ * become 4-wide nodes. */
+__global__ __launch_bounds__(256) void k_depth(int32_t n, const int32_t* __restrict__ parent, uint8_t* __restrict__ odd, int32_t* __restrict__ maxDepth)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t depth = 0;
+    if (i < n - 1)
+    {
+        int32_t p = parent[i];
+        while (p >= 0) { ++depth; p = parent[p]; }
+        odd[i] = (uint8_t)(depth & 1);
+    }
+    for (int o = 32; o > 0; o >>= 1) depth = max(depth, __shfl_xor(depth, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxDepth, depth);
+}
+
+struct WideSlot { float lo[3], hi[3]; int32_t child; };
+
+__device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
+    const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast, WideSlot* s)
+{
+    float4 lo, hi;
+    if (c >= n - 1)
+    {
+        const int32_t j = c - (n - 1);
+        const uint32_t t = vals[j];
+        lo = triLo[t]; hi = triHi[t];
+        s->child = ~((j << 3) | 0);
+    }
+    else
+    {
+        lo = nodeLo[c]; hi = nodeHi[c];
+        const int32_t first = rangeFirst[c], count = rangeLast[c] - first + 1;
+        s->child = (count <= PT_LEAF_MAX) ? ~((first << 3) | (count - 1)) : c;
+    }
+    s->lo[0] = lo.x; s->lo[1] = lo.y; s->lo[2] = lo.z;
+    s->hi[0] = hi.x; s->hi[1] = hi.y; s->hi[2] = hi.z;
+}
+
+__global__ __launch_bounds__(256) void k_emit_wide(int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
+    const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
+    const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast,
+    const uint8_t* __restrict__ odd, float4* __restrict__ wide)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (odd[i]) return;
+    if (i != 0 && (rangeLast[i] - rangeFirst[i] + 1) <= PT_LEAF_MAX) return;      /* collapsed into a leaf */
+    WideSlot slot[4];
+    int ns = 0;
+    const int32_t cs[2] = { child0[i], child1[i] };
+    for (int k = 0; k < 2; ++k)
+    {
+        const int32_t c = cs[k];
+        const bool inner = (c < n - 1) && ((rangeLast[c] - rangeFirst[c] + 1) > PT_LEAF_MAX);
+        if (inner)
+        {
+            wide_slot_from(child0[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
+            wide_slot_from(child1[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
+        }
+        else
+        {
+            wide_slot_from(c, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
+        }
+    }
+    for (; ns < 4; ++ns)
+    {
+        for (int a = 0; a < 3; ++a) { slot[ns].lo[a] = __builtin_inff(); slot[ns].hi[a] = -__builtin_inff(); }
+        slot[ns].child = PT_BVH_EMPTY;
+    }
+    float4* q = wide + (size_t)i * 8;
+    q[0] = make_float4(slot[0].lo[0], slot[1].lo[0], slot[2].lo[0], slot[3].lo[0]);
+    q[1] = make_float4(slot[0].lo[1], slot[1].lo[1], slot[2].lo[1], slot[3].lo[1]);
+    q[2] = make_float4(slot[0].lo[2], slot[1].lo[2], slot[2].lo[2], slot[3].lo[2]);
+    q[3] = make_float4(slot[0].hi[0], slot[1].hi[0], slot[2].hi[0], slot[3].hi[0]);
+    q[4] = make_float4(slot[0].hi[1], slot[1].hi[1], slot[2].hi[1], slot[3].hi[1]);
+    q[5] = make_float4(slot[0].hi[2], slot[1].hi[2], slot[2].hi[2], slot[3].hi[2]);
+    q[6] = make_float4(__int_as_float(slot[0].child), __int_as_float(slot[1].child), __int_as_float(slot[2].child), __int_as_float(slot[3].child));
+    q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+/* scenes of at most PT_LEAF_MAX triangles: one node, one leaf */
+__global__ void k_emit_single(int32_t n, const float4* __restrict__ triLo, const float4* __restrict__ triHi, float4* __restrict__ wide)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() };
+    float hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+    for (int32_t i = 0; i < n; ++i)
+    {
+        lo[0] = fminf(lo[0], triLo[i].x); lo[1] = fminf(lo[1], triLo[i].y); lo[2] = fminf(lo[2], triLo[i].z);
+        hi[0] = fmaxf(hi[0], triHi[i].x); hi[1] = fmaxf(hi[1], triHi[i].y); hi[2] = fmaxf(hi[2], triHi[i].z);
+    }
+    const float inf = __builtin_inff();
+    const int32_t leaf = n > 0 ? ~((0 << 3) | (n - 1)) : PT_BVH_EMPTY;
+    wide[0] = make_float4(lo[0], inf, inf, inf);
+    wide[1] = make_float4(lo[1], inf, inf, inf);
+    wide[2] = make_float4(lo[2], inf, inf, inf);
+    wide[3] = make_float4(hi[0], -inf, -inf, -inf);
+    wide[4] = make_float4(hi[1], -inf, -inf, -inf);
+    wide[5] = make_float4(hi[2], -inf, -inf, -inf);
+    wide[6] = make_float4(__int_as_float(leaf), __int_as_float(PT_BVH_EMPTY), __int_as_float(PT_BVH_EMPTY), __int_as_float(PT_BVH_EMPTY));
+    wide[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_emit_tris(const v4* __restrict__ positions, const uint32_t* __restrict__ vals,
+    int32_t n, float4* __restrict__ tris)
+{
+    const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t t = vals ? vals[j] : (uint32_t)j;
+    const v4 p0 = positions[t * 3 + 0], p1 = positions[t * 3 + 1], p2 = positions[t * 3 + 2];
+    tris[(size_t)j * 3 + 0] = make_float4(p0.x, p0.y, p0.z, __uint_as_float(t));
+    tris[(size_t)j * 3 + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
+    tris[(size_t)j * 3 + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+
+void BvhStorage::release()
+{
+    hipFree(nodes); hipFree(tris); hipFree(scratch);
+    nodes = nullptr; tris = nullptr; scratch = nullptr; scratchBytes = 0; capacityTris = 0;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream_t stream)
+{
+    const int32_t n = triCount;
+    const int32_t cap = n > 0 ? n : 1;
+    const int32_t numBlocks = (cap + kSortTile - 1) / kSortTile;
+    /* scratch layout */
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    const size_t oTriLo = take(sizeof(float4) * cap), oTriHi = take(sizeof(float4) * cap);
+    const size_t oKeysA = take(8 * (size_t)cap), oKeysB = take(8 * (size_t)cap);
+    const size_t oValsA = take(4 * (size_t)cap), oValsB = take(4 * (size_t)cap);
+    const size_t oCounts = take(4 * (size_t)256 * numBlocks), oTotals = take(4 * 256);
+    const size_t oChild0 = take(4 * (size_t)cap), oChild1 = take(4 * (size_t)cap);
+    const size_t oParent = take(4 * (size_t)(2 * cap)), oFirst = take(4 * (size_t)cap), oLast = take(4 * (size_t)cap);
+    const size_t oNodeLo = take(sizeof(float4) * cap), oNodeHi = take(sizeof(float4) * cap);
+    const size_t oFlags = take(4 * (size_t)cap), oOdd = take((size_t)cap), oBounds = take(64), oDepth = take(64);
+    const size_t need = off;
+    if (b->capacityTris < cap || b->scratchBytes < need)
+    {
+        b->release();
+        if (hipMalloc(&b->nodes, sizeof(float4) * 8 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
+        if (hipMalloc(&b->tris, sizeof(float4) * 3 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
+        if (hipMalloc(&b->scratch, need) != hipSuccess) return PIMGPU_E_NOMEM;
+        b->capacityTris = cap; b->scratchBytes = need;
+    }
+    char* s = (char*)b->scratch;
+    float4* triLo = (float4*)(s + oTriLo); float4* triHi = (float4*)(s + oTriHi);
+    uint64_t* keysA = (uint64_t*)(s + oKeysA); uint64_t* keysB = (uint64_t*)(s + oKeysB);
+    uint32_t* valsA = (uint32_t*)(s + oValsA); uint32_t* valsB = (uint32_t*)(s + oValsB);
+    uint32_t* counts = (uint32_t*)(s + oCounts); uint32_t* totals = (uint32_t*)(s + oTotals);
+    int32_t* child0 = (int32_t*)(s + oChild0); int32_t* child1 = (int32_t*)(s + oChild1);
+    int32_t* parent = (int32_t*)(s + oParent); int32_t* rangeFirst = (int32_t*)(s + oFirst); int32_t* rangeLast = (int32_t*)(s + oLast);
+    float4* nodeLo = (float4*)(s + oNodeLo); float4* nodeHi = (float4*)(s + oNodeHi);
+    uint32_t* flags = (uint32_t*)(s + oFlags); uint8_t* odd = (uint8_t*)(s + oOdd);
+    uint32_t* bounds = (uint32_t*)(s + oBounds); int32_t* depth = (int32_t*)(s + oDepth);
+
+    b->triCount = n;
+    b->nodeCount = n > 1 ? n - 1 : 1;
+    b->maxDepthDev = depth;
+    const int grid = (cap + 255) / 256;
+    hipMemsetAsync(depth, 0, 4, stream);
+    k_bounds_init<<<1, 64, 0, stream>>>(bounds);
+    if (n > 0) k_tri_bounds<<<grid, 256, 0, stream>>>(positionsDev, n, triLo, triHi, bounds);
+    if (n <= PT_LEAF_MAX)
+    {
+        k_emit_single<<<1, 64, 0, stream>>>(n, triLo, triHi, b->nodes);
+        if (n > 0) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, nullptr, n, b->tris);
+        return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
+    }
+    k_morton<<<grid, 256, 0, stream>>>(triLo, triHi, n, bounds, keysA, valsA);
+    uint64_t* kin = keysA; uint64_t* kout = keysB; uint32_t* vin = valsA; uint32_t* vout = valsB;
+    for (int shift = 0; shift < 64; shift += 8)
+    {
+        k_sort_hist<<<numBlocks, kSortThreads, 0, stream>>>(kin, n, shift, counts, numBlocks);
+        k_sort_scan<<<256, 256, 0, stream>>>(counts, numBlocks, totals);
+        k_sort_scatter<<<numBlocks, kSortThreads, 0, stream>>>(kin, vin, kout, vout, n, shift, counts, totals, numBlocks);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    /* 8 passes: result is back in the A buffers */
+    k_karras<<<grid, 256, 0, stream>>>(kin, n, child0, child1, parent, rangeFirst, rangeLast);
+    hipMemsetAsync(flags, 0, 4 * (size_t)n, stream);
+    k_refit<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, child0, child1, parent, nodeLo, nodeHi, flags);
+    k_depth<<<grid, 256, 0, stream>>>(n, parent, odd, depth);
+    k_emit_wide<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, nodeLo, nodeHi, child0, child1, rangeFirst, rangeLast, odd, b->nodes);
+    k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, vin, n, b->tris);
+    return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
+}
+
+} /* namespace pt */

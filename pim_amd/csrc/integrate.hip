@@ -1,0 +1,839 @@
+/*
+ * integrate.hip -- wavefront form of Pt_TraceRay / Pt_Trace / Pt_RayGen
+ * (rendering/path_tracer.c:2306-2416, 2514-2585, 2596-2644; "pt.c" below).
+ *
+ * The reference walks one path at a time: for b in 0..666 { russian roulette; rtcIntersect1;
+ * media; surface; direct light (one more rtcIntersect1); scatter }.  Here all paths of a batch
+ * advance one bounce together, and the two ray queries of a bounce are whole-batch launches of
+ * the traversal kernel (trace.hip):
+ *
+ *   init      one lane per pixel / ray: seed the Prng stream, generate the camera ray (AA + DOF),
+ *             draw the first roulette number, emit extension ray #0                  pt.c:2514-2553
+ *   loop b:   trace(ext)  -> shade_a: miss/sky, media, surface, emission, light-grid feedback,
+ *                            first half of EstimateDirect -> emits the NEE ray       pt.c:2333-2388
+ *             trace(nee)  -> shade_b: second half of EstimateDirect, Scatter_Principled, AOVs,
+ *                            roulette of bounce b+1, wave-ballot compaction of the
+ *                            survivors into the next queue + their extension rays    pt.c:2389-2407,2319-2331
+ *   resolve   running-mean accumulate into the PtTrace images                        pt.c:2547-2552
+ *
+ * Every path owns its Prng stream and the stages draw from it in the reference's order
+ * (SURVEY A.2), so the result of a path does not depend on how paths are batched.  Queues hold
+ * path slots; rays and hits are stored by QUEUE POSITION so the traversal kernel reads and
+ * writes them coalesced.  Queue lengths live in device memory: no host round trip per bounce.
+ * The rare rays in the middle of a stage (media in-scatter light ray, refraction thickness ray)
+ * are traced inline by the lane that needs them.
+ */
+#include "pt_host.h"
+#include "pt_api.h"
+#include "pt_scene_fn.h"
+
+#include <cstring>
+
+namespace pt {
+
+static constexpr int kShadeThreads = 256;
+
+/* nee0.x modes between shade_a and shade_b */
+#define PT_NEE_NONE   0     /* no direct-light ray this bounce */
+#define PT_NEE_LIGHT  1     /* light-sampling branch of EstimateDirect */
+#define PT_NEE_BRDF   2     /* BRDF-sampling branch */
+#define PT_NEE_MEDIA  3     /* the medium scattered the path: bounce already applied */
+#define PT_NEE_DEAD   4     /* path finished in shade_a */
+
+void WorkBuffers::release()
+{
+    hipFree(rayO); hipFree(rayD);
+    hipFree(ps.rng); hipFree(ps.ro); hipFree(ps.rd); hipFree(ps.atten); hipFree(ps.lum); hipFree(ps.albedo); hipFree(ps.normal);
+    hipFree(ps.nee0); hipFree(ps.nee1);
+    for (int i = 0; i < 2; ++i) { hipFree(extO[i]); hipFree(extD[i]); hipFree(queue[i]); }
+    hipFree(neeO); hipFree(neeD); hipFree(extHit); hipFree(neeHit); hipFree(counters); hipFree(stats); hipFree(results);
+    *this = WorkBuffers();
+}
+
+int WorkBuffers::ensure_rays(int64_t n)
+{
+    if (n <= rayCap) return PIMGPU_OK;
+    hipFree(rayO); hipFree(rayD); rayO = rayD = nullptr; rayCap = 0;
+    if (hipMalloc(&rayO, sizeof(float4) * n) != hipSuccess || hipMalloc(&rayD, sizeof(float4) * n) != hipSuccess)
+    { set_error("out of device memory for %lld rays", (long long)n); return PIMGPU_E_NOMEM; }
+    rayCap = n;
+    return PIMGPU_OK;
+}
+
+int WorkBuffers::ensure_paths(int64_t n)
+{
+    if (!counters)
+    {
+        PT_HIP(hipMalloc(&counters, 256));
+        PT_HIP(hipMalloc(&stats, 256));
+    }
+    if (n <= pathCap) return PIMGPU_OK;
+    const int64_t keepRay = rayCap; float4* kO = rayO; float4* kD = rayD;
+    int32_t* kc = counters; unsigned long long* ks = stats;
+    rayO = rayD = nullptr; counters = nullptr; stats = nullptr;
+    release();
+    rayO = kO; rayD = kD; rayCap = keepRay; counters = kc; stats = ks;
+    bool ok = true;
+    auto A = [&](auto** p, size_t elem) { if (ok && hipMalloc((void**)p, elem * (size_t)n) != hipSuccess) ok = false; };
+    A(&ps.rng, sizeof(uint4)); A(&ps.ro, sizeof(float4)); A(&ps.rd, sizeof(float4)); A(&ps.atten, sizeof(float4));
+    A(&ps.lum, sizeof(float4)); A(&ps.albedo, sizeof(float4)); A(&ps.normal, sizeof(float4));
+    A(&ps.nee0, sizeof(float4)); A(&ps.nee1, sizeof(float4));
+    for (int i = 0; i < 2; ++i) { A(&extO[i], sizeof(float4)); A(&extD[i], sizeof(float4)); A(&queue[i], sizeof(int32_t)); }
+    A(&neeO, sizeof(float4)); A(&neeD, sizeof(float4)); A(&extHit, sizeof(DHit)); A(&neeHit, sizeof(DHit)); A(&results, sizeof(PimResult));
+    if (!ok) { set_error("out of device memory for %lld paths", (long long)n); return PIMGPU_E_NOMEM; }
+    pathCap = n;
+    return PIMGPU_OK;
+}
+
+__global__ __launch_bounds__(256) void k_pack_rays(const float4* __restrict__ ro, const float4* __restrict__ rd,
+    const float* __restrict__ tNear, const float* __restrict__ tFar, int32_t n, float4* __restrict__ rayO, float4* __restrict__ rayD)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 o = ro[i], d = rd[i];
+    rayO[i] = make_float4(o.x, o.y, o.z, tNear ? tNear[i] : 0.0f);
+    rayD[i] = make_float4(d.x, d.y, d.z, tFar ? tFar[i] : PT_RCP_EPS);
+}
+
+int pack_rays(const float4* ro, const float4* rd, const float* tNear, const float* tFar, int32_t n, float4* rayO, float4* rayD, hipStream_t stream)
+{
+    k_pack_rays<<<(n + 255) / 256, 256, 0, stream>>>(ro, rd, tNear, tFar, n, rayO, rayD);
+    PT_HIP(hipGetLastError());
+    return PIMGPU_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* device helpers                                                                                  */
+
+struct StageArgs
+{
+    PathState ps;
+    const int32_t* queueIn; int32_t* queueOut;
+    int32_t* counters;              /* [0], [1]: lengths of queue[0], queue[1] */
+    int32_t inSel;                  /* which queue is the input of this bounce */
+    const float4* extD;             /* unused by the stages (rd is path state) */
+    const DHit* extHit; const DHit* neeHit;
+    float4* neeO; float4* neeD;
+    float4* extOOut; float4* extDOut;
+    PimResult* results;
+    unsigned long long* stats;
+    int32_t bounce, bounceLimit;
+};
+
+__device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st4(float4* p, int64_t i, v4 v) { p[i] = make_float4(v.x, v.y, v.z, v.w); }
+
+/* the tail of Pt_TraceRay, pt.c:2409-2415 */
+__device__ __forceinline__ void path_finish(const StageArgs& a, int32_t slot, const Ctx& ctx, v4 lum, float resultWeight, v4 albedoAcc, v4 normalAcc)
+{
+    const float sc = 1.0f / f1_max(resultWeight, PT_EPS);
+    PimResult r;
+    r.color[0] = lum.x; r.color[1] = lum.y; r.color[2] = lum.z;
+    r.albedo[0] = albedoAcc.x * sc; r.albedo[1] = albedoAcc.y * sc; r.albedo[2] = albedoAcc.z * sc;
+    r.normal[0] = normalAcc.x * sc; r.normal[1] = normalAcc.y * sc; r.normal[2] = normalAcc.z * sc;
+    a.results[slot] = r;
+    a.ps.rng[slot] = make_uint4(ctx.rng.x, ctx.rng.y, ctx.rng.z, ctx.rng.w);
+}
+
+/* russian roulette at the top of a bounce, pt.c:2321-2331 */
+__device__ __forceinline__ bool roulette(Ctx& ctx, v4& attenuation)
+{
+    const float p = f1_sat(f4_avglum(attenuation));
+    if (Sample1D(ctx) < p) { attenuation = f4_divs(attenuation, p); return true; }
+    return false;
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+/* a fresh path in slot `slot`: Pt_TraceRay's locals (pt.c:2310-2317) + roulette of bounce 0 + extension ray 0 */
+__device__ __forceinline__ void path_start(const PathState& ps, float4* extO, float4* extD, int32_t* queue, int32_t slot, Ctx& ctx, v4 ro, v4 rd)
+{
+    v4 attenuation = f4_s(1.0f);
+    const bool alive = roulette(ctx, attenuation);   /* p == 1: always survives; the draw is consumed as in the reference */
+    (void)alive;
+    ps.rng[slot] = make_uint4(ctx.rng.x, ctx.rng.y, ctx.rng.z, ctx.rng.w);
+    ps.ro[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    ps.rd[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+    ps.atten[slot] = make_float4(attenuation.x, attenuation.y, attenuation.z, 0.0f);
+    ps.lum[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    extO[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    extD[slot] = make_float4(rd.x, rd.y, rd.z, PT_RCP_EPS);
+    queue[slot] = slot;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* init kernels                                                                                    */
+
+struct CameraArgs
+{
+    v4 eye, right, up, fwd; v2 slope;
+    PimDofInfo dof;
+    int32_t width, height;
+    uint32_t sampleIndex, seed;
+};
+
+/* CalculateDof, pt.c:2418-2452 */
+__device__ __forceinline__ void CalculateDof(Ctx& ctx, const PimDofInfo& dof, v4 right, v4 up, v4 fwd, v4* ro, v4* rd)
+{
+    v2 offset;
+    {
+        const uint32_t side = rng_u32(&ctx.rng);
+        const v2 Xi = Sample2D(ctx);
+        if (dof.bladeCount == 666) offset = SamplePentagram(Xi, side);
+        else offset = SampleNGon(Xi, side, (uint32_t)dof.bladeCount, dof.bladeRot);
+    }
+    offset = f2_muls(offset, dof.aperture);
+    const float t = f1_lerp(dof.focalLength / f4_dot3(*rd, fwd), dof.focalLength, dof.focalPlaneCurvature);
+    const v4 focusPos = f4_add(*ro, f4_muls(*rd, t));
+    const v4 aperturePos = f4_add(*ro, f4_add(f4_muls(right, offset.x), f4_muls(up, offset.y)));
+    *ro = aperturePos;
+    *rd = f4_normalize3(f4_sub(focusPos, aperturePos));
+}
+
+/* TraceFn up to Pt_TraceRay, pt.c:2514-2545 */
+__global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, float4* extD, int32_t* queue, CameraArgs c)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.width * c.height) return;
+    const int32_t cx = i % c.width, cy = i / c.width;
+    const float rcpX = 1.0f / (float)c.width, rcpY = 1.0f / (float)c.height;
+    Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+    ctx.rng = pcg4((uint32_t)cx, (uint32_t)cy, c.sampleIndex, c.seed ^ PT_TAG_PIXEL);
+    const v2 baseUv = f2_v((cx + 0.5f) * rcpX, (cy + 0.5f) * rcpY);
+    const v2 aa = SampleGaussPixelFilter(Sample2D(ctx), 1.0f);
+    const v2 rayUv = f2_add(baseUv, f2_mul(aa, f2_v(rcpX, rcpY)));
+    v4 ro = c.eye;
+    v4 rd = proj_dir(c.right, c.up, c.fwd, c.slope, f2_v(rayUv.x * 2.0f - 1.0f, rayUv.y * 2.0f - 1.0f));
+    CalculateDof(ctx, c.dof, c.right, c.up, c.fwd, &ro, &rd);
+    path_start(ps, extO, extD, queue, i, ctx, ro, rd);
+}
+
+/* batched Pt_TraceRay: rays given (mode 0) or RayGenFn's uniform sphere directions (mode 1, pt.c:2596-2612) */
+__global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, float4* extD, int32_t* queue,
+    const float4* __restrict__ ro, const float4* __restrict__ rd, v4 origin, float4* __restrict__ directionsOut,
+    int32_t n, uint32_t sampleIndex, uint32_t seed)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+    ctx.rng = pcg4((uint32_t)i, sampleIndex, seed, PT_TAG_RAY);
+    v4 o, d;
+    if (ro) { o = ld4(ro, i); d = ld4(rd, i); }
+    else
+    {
+        o = origin;
+        d = SampleUnitSphere(Sample2D(ctx));
+        directionsOut[i] = make_float4(d.x, d.y, d.z, d.w);
+    }
+    path_start(ps, extO, extD, queue, i, ctx, o, d);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* shade_a: everything of a bounce between the extension hit and the direct-light ray              */
+
+__global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a)
+{
+    const int32_t count = a.counters[a.inSel];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        a.counters[a.inSel ^ 1] = 0;                         /* output queue of shade_b starts empty */
+        atomicAdd(&a.stats[0], (unsigned long long)count);   /* extension rays of this bounce */
+    }
+    uint32_t shadow = 0, other = 0; bool overflow = false;
+    for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    {
+        const int32_t pos = base + threadIdx.x;
+        if (pos >= count) continue;
+        const int32_t slot = a.queueIn[pos];
+        Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+        { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
+        const v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
+        v4 attenuation = ld4(a.ps.atten, slot);
+        float resultWeight = attenuation.w;
+        v4 luminance = ld4(a.ps.lum, slot);
+        const uint32_t prevFlags = __float_as_uint(luminance.w);
+
+        float4 nee0 = make_float4(__int_as_float(PT_NEE_DEAD), 0.0f, 0.0f, 0.0f);
+        float4 nee1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nD = make_float4(0.0f, 0.0f, 1.0f, -1.0f);   /* tFar < tNear: no ray */
+        bool finished = false;
+
+        const RayHit hit = make_rayhit(s, rd, a.extHit[pos]);
+        if (hit.type == PIM_HIT_NOTHING)
+        {
+            luminance = f4_add(luminance, f4_mul(attenuation, GetSky(s, rd)));        /* pt.c:2334-2338 */
+            finished = true;
+        }
+        else if ((hit.type == PIM_HIT_BACKFACE) && !(hit.flags & PIM_MATFLAG_REFRACTIVE))
+        {
+            finished = true;                                                          /* pt.c:2339-2343 */
+        }
+        else
+        {
+            const Scatter ms = ScatterRay(ctx, s, ro, rd, hit.wuvt.w);                /* pt.c:2346-2367 */
+            if (ms.pdf > PT_EPS)
+            {
+                luminance = f4_add(luminance, f4_mul(attenuation, ms.luminance));
+                attenuation = f4_mul(attenuation, f4_divs(ms.attenuation, ms.pdf));
+                v4 albedoAcc = ld4(a.ps.albedo, slot), normalAcc = ld4(a.ps.normal, slot);
+                {
+                    const v4 al = f4_muls(attenuation, 1.0f / PT_TAU);
+                    const float w = f1_sat(1.0f - f4_avglum(al));
+                    resultWeight += w;
+                    albedoAcc = f4_v(albedoAcc.x + al.x * w, albedoAcc.y + al.y * w, albedoAcc.z + al.z * w, 0.0f);
+                    const v4 nr = f4_neg(rd);
+                    normalAcc = f4_v(normalAcc.x + nr.x * w, normalAcc.y + nr.y * w, normalAcc.z + nr.z * w, 0.0f);
+                }
+                st4(a.ps.albedo, slot, albedoAcc); st4(a.ps.normal, slot, normalAcc);
+                st4(a.ps.ro, slot, ms.pos);
+                a.ps.rd[slot] = make_float4(ms.dir.x, ms.dir.y, ms.dir.z, 0.0f);
+                luminance.w = __uint_as_float(0u);                                    /* prevFlags = 0 */
+                nee0.x = __int_as_float(PT_NEE_MEDIA);
+            }
+            else
+            {
+                attenuation = f4_mul(attenuation, ms.attenuation);
+                const SurfHit surf = GetSurface(s, rd, hit);                          /* pt.c:2369 */
+                if (a.bounce > 0) LightOnHit(s, ro, surf.emission, hit.iVert);        /* pt.c:2370-2373 */
+                if ((a.bounce == 0) || (prevFlags & PIM_MATFLAG_REFRACTIVE))
+                {
+                    const float keep = luminance.w;
+                    luminance = f4_add(luminance, f4_mul(surf.emission, attenuation)); /* pt.c:2375-2378 */
+                    luminance.w = keep;
+                }
+                if (hit.flags & PIM_MATFLAG_SKY)
+                {
+                    finished = true;                                                  /* pt.c:2380-2383 */
+                }
+                else
+                {
+                    /* EstimateDirect up to its ray, pt.c:1849-1870 / 1899-1906 */
+                    nee0.x = __int_as_float(PT_NEE_NONE);
+                    if (!(surf.flags & PIM_MATFLAG_REFRACTIVE))
+                    {
+                        const float pRough = f1_lerp(0.05f, 0.95f, surf.roughness);
+                        const float pSmooth = 1.0f - pRough;
+                        if (Sample1D(ctx) < pRough)
+                        {
+                            int32_t iVert; float selectPdf;
+                            if (LightSelect(ctx, s, surf.P, &iVert, &selectPdf))
+                            {
+                                if (hit.iVert != iVert)
+                                {
+                                    const LightRay lr = SampleLight_ray(ctx, s, surf.P, iVert);
+                                    nee0 = make_float4(__int_as_float(PT_NEE_LIGHT), __int_as_float(iVert), selectPdf, lr.distSq);
+                                    nO = make_float4(surf.P.x, surf.P.y, surf.P.z, 0.0f);
+                                    nD = make_float4(lr.rd.x, lr.rd.y, lr.rd.z, lr.distance + 0.01f * PT_MILLI);
+                                    ++shadow;
+                                }
+                            }
+                        }
+                        else
+                        {
+                            const Scatter sample = Scatter_Principled(ctx, s, surf, rd);
+                            const float brdfPdf = sample.pdf * pSmooth;
+                            if (brdfPdf > PT_EPS)
+                            {
+                                nee0.x = __int_as_float(PT_NEE_BRDF);
+                                nee1 = make_float4(sample.attenuation.x, sample.attenuation.y, sample.attenuation.z, sample.pdf);
+                                nO = make_float4(surf.P.x, surf.P.y, surf.P.z, 0.0f);
+                                nD = make_float4(sample.dir.x, sample.dir.y, sample.dir.z, PT_RCP_EPS);
+                                ++shadow;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (finished)
+        {
+            path_finish(a, slot, ctx, luminance, resultWeight, ld4(a.ps.albedo, slot), ld4(a.ps.normal, slot));
+            nee0.x = __int_as_float(PT_NEE_DEAD);
+        }
+        else
+        {
+            a.ps.rng[slot] = make_uint4(ctx.rng.x, ctx.rng.y, ctx.rng.z, ctx.rng.w);
+            a.ps.atten[slot] = make_float4(attenuation.x, attenuation.y, attenuation.z, resultWeight);
+            a.ps.lum[slot] = make_float4(luminance.x, luminance.y, luminance.z, luminance.w);
+        }
+        a.ps.nee0[slot] = nee0; a.ps.nee1[slot] = nee1;
+        a.neeO[pos] = nO; a.neeD[pos] = nD;
+        other += ctx.otherRays; overflow |= ctx.overflow;
+    }
+    wave_add(&a.stats[1], shadow);
+    wave_add(&a.stats[2], other);
+    if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* shade_b: from the direct-light hit to the next extension ray                                    */
+
+__global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a)
+{
+    const int32_t count = a.counters[a.inSel];
+    int32_t* countOut = &a.counters[a.inSel ^ 1];
+    uint32_t other = 0; bool overflow = false;
+    const int lane = threadIdx.x & 63;
+    const uint64_t ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    {
+        const int32_t pos = base + threadIdx.x;
+        bool alive = false;
+        int32_t slot = 0;
+        v4 ro = f4_s(0.0f), rd = f4_s(0.0f);
+        if (pos < count)
+        {
+            slot = a.queueIn[pos];
+            const float4 nee0 = a.ps.nee0[slot];
+            const int32_t mode = __float_as_int(nee0.x);
+            if (mode != PT_NEE_DEAD)
+            {
+                Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+                { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
+                ro = ld4(a.ps.ro, slot); rd = ld4(a.ps.rd, slot);
+                v4 attenuation = ld4(a.ps.atten, slot);
+                float resultWeight = attenuation.w;
+                v4 luminance = ld4(a.ps.lum, slot);
+                uint32_t prevFlags = __float_as_uint(luminance.w);
+                v4 albedoAcc = ld4(a.ps.albedo, slot), normalAcc = ld4(a.ps.normal, slot);
+                bool finished = false;
+                if (mode != PT_NEE_MEDIA)
+                {
+                    const RayHit hit = make_rayhit(s, rd, a.extHit[pos]);
+                    const SurfHit surf = GetSurface(s, rd, hit);
+                    /* EstimateDirect after its ray, pt.c:1871-1897 / 1907-1918 */
+                    v4 Li = f4_s(0.0f);
+                    if (mode == PT_NEE_LIGHT || mode == PT_NEE_BRDF)
+                    {
+                        const float pRough = f1_lerp(0.05f, 0.95f, surf.roughness);
+                        const float pSmooth = 1.0f - pRough;
+                        const float4 nD = a.neeD[pos];
+                        const v4 nrd = f4_v(nD.x, nD.y, nD.z, 0.0f);
+                        const RayHit nh = make_rayhit(s, nrd, a.neeHit[pos]);
+                        if (mode == PT_NEE_LIGHT)
+                        {
+                            const int32_t iVert = __float_as_int(nee0.y);
+                            const float selectPdf = nee0.z;
+                            const LightSample sample = SampleLight_finish(ctx, s, surf.P, iVert, nrd, nee0.w, nh);
+                            v4 L = sample.luminance;
+                            const float lightPdf = sample.pdf * selectPdf * pRough;
+                            if ((lightPdf > PT_EPS) && (f4_hmax3(L) > PT_EPS))
+                            {
+                                const v4 brdf = Eval_Principled(s, surf, rd, nrd);
+                                L = f4_mul(L, brdf);
+                                const float brdfPdf = brdf.w * pSmooth;
+                                if (brdfPdf > PT_EPS)
+                                {
+                                    L = f4_muls(L, PowerHeuristic(lightPdf, brdfPdf) / lightPdf);
+                                    Li = f4_add(Li, L);
+                                }
+                            }
+                        }
+                        else
+                        {
+                            const float4 nee1 = a.ps.nee1[slot];
+                            const v4 sampleAtt = f4_v(nee1.x, nee1.y, nee1.z, nee1.w);
+                            const float brdfPdf = nee1.w * pSmooth;
+                            /* LightEvalPdf after its ray, pt.c:1838-1846 */
+                            float lightPdf = 0.0f;
+                            if (nh.type != PIM_HIT_NOTHING)
+                            {
+                                const float cosTheta = f1_abs(f4_dot3(nrd, nh.normal));
+                                const float area = GetArea(s, nh.iVert);
+                                const float distSq = f1_max(PT_EPS, nh.wuvt.w * nh.wuvt.w);
+                                lightPdf = LightPdf(area, cosTheta, distSq);
+                            }
+                            lightPdf *= pRough;
+                            if (lightPdf > PT_EPS)
+                            {
+                                lightPdf *= LightSelectPdf(s, nh.iVert, surf.P);
+                                v4 L = f4_mul(GetEmission(s, nrd, nh), sampleAtt);
+                                if (f4_hmax3(L) > PT_EPS)
+                                {
+                                    L = f4_muls(L, PowerHeuristic(brdfPdf, lightPdf) / brdfPdf);
+                                    L = f4_mul(L, CalcTransmittance(ctx, s, surf.P, nrd, nh.wuvt.w));
+                                    Li = f4_add(Li, L);
+                                }
+                            }
+                        }
+                    }
+                    {
+                        const float keep = luminance.w;
+                        luminance = f4_add(luminance, f4_mul(Li, attenuation));      /* pt.c:2385-2388 */
+                        luminance.w = keep;
+                    }
+                    const Scatter scatter = Scatter_Principled(ctx, s, surf, rd);      /* pt.c:2390 */
+                    if (!(scatter.pdf > PT_EPS))
+                    {
+                        finished = true;                                              /* pt.c:2391-2394 */
+                    }
+                    else
+                    {
+                        ro = scatter.pos; rd = scatter.dir;
+                        attenuation = f4_mul(attenuation, f4_divs(scatter.attenuation, scatter.pdf));
+                        prevFlags = surf.flags;
+                        const v4 al = f4_muls(attenuation, 1.0f / PT_PI);
+                        const float w = f1_sat(1.0f - f4_avglum(al));
+                        resultWeight += w;
+                        albedoAcc = f4_v(albedoAcc.x + surf.albedo.x * w, albedoAcc.y + surf.albedo.y * w, albedoAcc.z + surf.albedo.z * w, 0.0f);
+                        normalAcc = f4_v(normalAcc.x + surf.N.x * w, normalAcc.y + surf.N.y * w, normalAcc.z + surf.N.z * w, 0.0f);
+                    }
+                }
+                /* top of bounce b+1, pt.c:2319-2331 */
+                if (!finished)
+                {
+                    if (a.bounce + 1 >= a.bounceLimit) finished = true;
+                    else if (!roulette(ctx, attenuation)) finished = true;
+                }
+                if (finished)
+                {
+                    path_finish(a, slot, ctx, luminance, resultWeight, albedoAcc, normalAcc);
+                }
+                else
+                {
+                    alive = true;
+                    a.ps.rng[slot] = make_uint4(ctx.rng.x, ctx.rng.y, ctx.rng.z, ctx.rng.w);
+                    a.ps.ro[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                    a.ps.rd[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+                    a.ps.atten[slot] = make_float4(attenuation.x, attenuation.y, attenuation.z, resultWeight);
+                    a.ps.lum[slot] = make_float4(luminance.x, luminance.y, luminance.z, __uint_as_float(prevFlags));
+                    st4(a.ps.albedo, slot, albedoAcc); st4(a.ps.normal, slot, normalAcc);
+                }
+                other += ctx.otherRays; overflow |= ctx.overflow;
+            }
+        }
+        /* russian-roulette compaction: survivors of this wave take consecutive queue positions */
+        const uint64_t m = __ballot(alive);
+        if (m)
+        {
+            const int leader = __ffsll((long long)m) - 1;
+            int32_t q0 = 0;
+            if (lane == leader) q0 = atomicAdd(countOut, (int32_t)__popcll(m));
+            q0 = __shfl(q0, leader, 64);
+            if (alive)
+            {
+                const int32_t q = q0 + (int32_t)__popcll(m & ltMask);
+                a.queueOut[q] = slot;
+                a.extOOut[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                a.extDOut[q] = make_float4(rd.x, rd.y, rd.z, PT_RCP_EPS);
+            }
+        }
+    }
+    wave_add(&a.stats[2], other);
+    if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
+}
+
+/* paths still queued when the host stops the loop (bounce limit reached inside shade_b never leaves any;
+ * this covers maxBounces == 0 style early stops): not needed -- shade_b finishes every path at the limit. */
+
+/* TraceFn's accumulate, pt.c:2547-2552 */
+__global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restrict__ results, int32_t n, float sampleWeight,
+    float* __restrict__ color, float* __restrict__ albedo, float* __restrict__ normal)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PimResult r = results[i];
+    for (int k = 0; k < 3; ++k)
+    {
+        color[i * 3 + k] = f1_lerp(color[i * 3 + k], r.color[k], sampleWeight);
+        albedo[i * 3 + k] = f1_lerp(albedo[i * 3 + k], r.albedo[k], sampleWeight);
+        normal[i * 3 + k] = f1_lerp(normal[i * 3 + k], r.normal[k], sampleWeight);
+    }
+}
+
+/* CalcStdDev, render_system.c:1374-1394: serial fp32 accumulation in pixel order (one lane: the
+ * summation order is part of the result) */
+__global__ void k_stddev(const float* __restrict__ color, int32_t len, float* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float meanWeight = 1.0f / len;
+    const float varianceWeight = 1.0f / (len - 1);
+    float mean = 0.0f;
+    for (int32_t i = 0; i < len; ++i)
+    {
+        const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
+        mean += lum * meanWeight;
+    }
+    float variance = 0.0f;
+    for (int32_t i = 0; i < len; ++i)
+    {
+        const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
+        const float err = lum - mean;
+        variance += varianceWeight * (err * err);
+    }
+    out[0] = mean;
+    out[1] = pt_sqrt(variance);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* host: the bounce loop                                                                           */
+
+int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
+{
+    WorkBuffers& w = g_lib.work;
+    hipStream_t st = g_lib.stream;
+    const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
+    const int32_t init[2] = { n, 0 };
+    PT_HIP(hipMemcpyAsync(w.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(w.stats, 0, 64, st));
+    const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * 8, ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    float traceMs = 0.0f;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    const bool timeTrace = traceMsOut != nullptr;
+    int rc = PIMGPU_OK;
+    for (int32_t b = 0; b < bounceLimit; ++b)
+    {
+        const int in = b & 1, out = in ^ 1;
+        StageArgs a;
+        a.ps = w.ps; a.queueIn = w.queue[in]; a.queueOut = w.queue[out]; a.counters = w.counters; a.inSel = in;
+        a.extD = w.extD[in]; a.extHit = w.extHit; a.neeHit = w.neeHit; a.neeO = w.neeO; a.neeD = w.neeD;
+        a.extOOut = w.extO[out]; a.extDOut = w.extD[out]; a.results = w.results; a.stats = w.stats;
+        a.bounce = b; a.bounceLimit = bounceLimit;
+        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
+        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[in], w.extD[in], w.extHit, n, w.counters + in, st))) break;
+        if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
+        k_shade_a<<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
+        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.neeO, w.neeD, w.neeHit, n, w.counters + in, st))) break;
+        if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
+        k_shade_b<<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
+        /* roulette-only termination (maxBounces <= 0): look at the queue length now and then */
+        if (bounceLimit == 666 && b >= 7 && (b % 4) == 3)
+        {
+            int32_t c[2];
+            PT_HIP(hipMemcpyAsync(c, w.counters, sizeof(c), hipMemcpyDeviceToHost, st));
+            PT_HIP(hipStreamSynchronize(st));
+            if (c[out] == 0) break;
+        }
+    }
+    if (rc) return rc;
+    unsigned long long hs[8];
+    PT_HIP(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    for (auto& e : events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow"); return PIMGPU_E_LIMIT; }
+    if (statsOut)
+    {
+        statsOut->extensionRays += hs[0]; statsOut->shadowRays += hs[1]; statsOut->otherRays += hs[2];
+        statsOut->paths += (uint64_t)n;
+    }
+    if (traceMsOut) *traceMsOut = traceMs;
+    return PIMGPU_OK;
+}
+
+} /* namespace pt */
+
+using namespace pt;
+
+extern "C" {
+
+int pimgpu_trace_create(int32_t width, int32_t height, PimTrace** out)
+{
+    if (out) *out = nullptr;
+    int rc = check_ready(); if (rc) return rc;
+    if (!out || width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 28)) { set_error("trace_create: bad size %dx%d", width, height); return PIMGPU_E_INVALID; }
+    PimTrace* t = new PimTrace();
+    t->width = width; t->height = height;
+    const size_t bytes = sizeof(float) * 3 * (size_t)width * height;
+    if (hipMalloc(&t->color, bytes) != hipSuccess || hipMalloc(&t->albedo, bytes) != hipSuccess || hipMalloc(&t->normal, bytes) != hipSuccess)
+    {
+        hipFree(t->color); hipFree(t->albedo); hipFree(t->normal); delete t;
+        set_error("trace_create: out of device memory"); return PIMGPU_E_NOMEM;
+    }
+    *out = t;
+    return pimgpu_trace_clear(t);
+}
+
+int pimgpu_trace_destroy(PimTrace* t)
+{
+    if (!t) return PIMGPU_OK;
+    if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
+    hipFree(t->color); hipFree(t->albedo); hipFree(t->normal);
+    delete t;
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_clear(PimTrace* t)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!t) { set_error("trace_clear: NULL trace"); return PIMGPU_E_INVALID; }
+    const size_t bytes = sizeof(float) * 3 * (size_t)t->width * t->height;
+    PT_HIP(hipMemsetAsync(t->color, 0, bytes, g_lib.stream));
+    PT_HIP(hipMemsetAsync(t->albedo, 0, bytes, g_lib.stream));
+    PT_HIP(hipMemsetAsync(t->normal, 0, bytes, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    memset(&t->stats, 0, sizeof(t->stats));
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !t || !cam || !dof || !p) { set_error("trace_image: NULL argument"); return PIMGPU_E_INVALID; }
+    if (dof->bladeCount <= 0) { set_error("trace_image: dof.bladeCount must be positive"); return PIMGPU_E_INVALID; }
+    hipStream_t st = g_lib.stream;
+    const int32_t n = t->width * t->height;
+    WorkBuffers& w = g_lib.work;
+    if ((rc = w.ensure_paths(n))) return rc;
+    hipEvent_t e0, e1;
+    PT_HIP(hipEventCreate(&e0)); PT_HIP(hipEventCreate(&e1));
+    PT_HIP(hipEventRecord(e0, st));
+    if (p->updateDists) { if ((rc = update_dists(scene->d, st))) return rc; }      /* PtScene_Update, pt.c:1034 */
+
+    const v4 rot = f4_v(cam->rotation[0], cam->rotation[1], cam->rotation[2], cam->rotation[3]);
+    const v4 eye = f4_v(cam->position[0], cam->position[1], cam->position[2], cam->position[3]);
+    uint64_t otherRays = 0;
+    if (dof->autoFocus)                                                             /* DofUpdate, pt.c:2485-2503 */
+    {
+        const v4 fwd = quat_fwd(rot);
+        const float4 ro = make_float4(eye.x, eye.y, eye.z, 0.0f), rd = make_float4(fwd.x, fwd.y, fwd.z, PT_RCP_EPS);
+        PT_HIP(hipMemcpyAsync(w.extO[0], &ro, sizeof(ro), hipMemcpyHostToDevice, st));
+        PT_HIP(hipMemcpyAsync(w.extD[0], &rd, sizeof(rd), hipMemcpyHostToDevice, st));
+        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[0], w.extD[0], w.extHit, 1, nullptr, st))) return rc;
+        DHit h;
+        PT_HIP(hipMemcpyAsync(&h, w.extHit, sizeof(h), hipMemcpyDeviceToHost, st));
+        PT_HIP(hipStreamSynchronize(st));
+        otherRays = 1;
+        if (h.prim >= 0 && h.t > 0.0f)
+        {
+            const float tt = 1.0f - pl_expf(-p->frameDt * dof->autoFocusSpeed);
+            dof->focalLength = f1_lerp(dof->focalLength, h.t, tt);
+        }
+    }
+    CameraArgs c;
+    c.eye = eye; c.right = quat_right(rot); c.up = quat_up(rot); c.fwd = quat_fwd(rot);
+    {
+        const float fovy = f1_radians(cam->fovy), aspect = (float)t->width / (float)t->height;
+        const float tn = pl_tanf(fovy * 0.5f);                                      /* proj_slope, frustum.h:26-30 */
+        c.slope = f2_v(aspect * tn, tn);
+    }
+    c.dof = *dof; c.width = t->width; c.height = t->height; c.sampleIndex = p->sampleIndex; c.seed = p->seed;
+    k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
+    PimTraceStats stats; memset(&stats, 0, sizeof(stats));
+    float traceMs = 0.0f;
+    if ((rc = integrate_paths(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr))) return rc;
+    k_resolve_image<<<(n + 255) / 256, 256, 0, st>>>(w.results, n, p->sampleWeight, t->color, t->albedo, t->normal);
+    PT_HIP(hipEventRecord(e1, st));
+    PT_HIP(hipEventSynchronize(e1));
+    float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    stats.otherRays += otherRays;
+    stats.traceMs = traceMs; stats.totalMs = totalMs;
+    stats.bounces = 0;
+    t->stats = stats;
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_download(const PimTrace* t, float* color, float* albedo, float* normal)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!t) { set_error("trace_download: NULL trace"); return PIMGPU_E_INVALID; }
+    const size_t bytes = sizeof(float) * 3 * (size_t)t->width * t->height;
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    if (color) PT_HIP(hipMemcpy(color, t->color, bytes, hipMemcpyDeviceToHost));
+    if (albedo) PT_HIP(hipMemcpy(albedo, t->albedo, bytes, hipMemcpyDeviceToHost));
+    if (normal) PT_HIP(hipMemcpy(normal, t->normal, bytes, hipMemcpyDeviceToHost));
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_buffers(const PimTrace* t, void** colorDev, void** albedoDev, void** normalDev)
+{
+    if (!t) { set_error("trace_buffers: NULL trace"); return PIMGPU_E_INVALID; }
+    if (colorDev) *colorDev = t->color;
+    if (albedoDev) *albedoDev = t->albedo;
+    if (normalDev) *normalDev = t->normal;
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!t) { set_error("trace_stddev: NULL trace"); return PIMGPU_E_INVALID; }
+    float* outDev = (float*)g_lib.trace.status + 16;       /* spare words of the status block */
+    k_stddev<<<1, 64, 0, g_lib.stream>>>(t->color, t->width * t->height, outDev);
+    float h[2];
+    PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    if (meanOut) *meanOut = h[0];
+    if (stddevOut) *stddevOut = h[1];
+    return PIMGPU_OK;
+}
+
+int pimgpu_trace_stats(const PimTrace* t, PimTraceStats* out)
+{
+    if (!t || !out) { set_error("trace_stats: NULL argument"); return PIMGPU_E_INVALID; }
+    *out = t->stats;
+    return PIMGPU_OK;
+}
+
+/* batched Pt_TraceRay / Pt_RayGen */
+static int trace_rays_common(PimScene* scene, const float* ro, const float* rd, const float* origin, int32_t n,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, PimResult* out, float* colors, float* directions)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || n < 0) { set_error("trace_rays: bad argument"); return PIMGPU_E_INVALID; }
+    if (n == 0) return PIMGPU_OK;
+    hipStream_t st = g_lib.stream;
+    WorkBuffers& w = g_lib.work;
+    if ((rc = w.ensure_paths(n))) return rc;
+    float4 *roDev = nullptr, *rdDev = nullptr, *dirDev = nullptr;
+    auto cleanup = [&]() { hipFree(roDev); hipFree(rdDev); hipFree(dirDev); };
+    v4 org = f4_s(0.0f);
+    if (ro)
+    {
+        if (hipMalloc(&roDev, sizeof(float4) * (size_t)n) != hipSuccess || hipMalloc(&rdDev, sizeof(float4) * (size_t)n) != hipSuccess)
+        { cleanup(); set_error("trace_rays: out of device memory"); return PIMGPU_E_NOMEM; }
+        hipMemcpyAsync(roDev, ro, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(rdDev, rd, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, st);
+    }
+    else
+    {
+        if (hipMalloc(&dirDev, sizeof(float4) * (size_t)n) != hipSuccess) { set_error("raygen: out of device memory"); return PIMGPU_E_NOMEM; }
+        org = f4_v(origin[0], origin[1], origin[2], origin[3]);
+    }
+    k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], roDev, rdDev, org, dirDev, n, sampleIndex, seed);
+    rc = integrate_paths(scene, n, maxBounces, nullptr, nullptr);
+    if (!rc)
+    {
+        if (out) hipMemcpyAsync(out, w.results, sizeof(PimResult) * (size_t)n, hipMemcpyDeviceToHost, st);
+        else
+        {
+            std::vector<PimResult> res((size_t)n);
+            hipMemcpyAsync(res.data(), w.results, sizeof(PimResult) * (size_t)n, hipMemcpyDeviceToHost, st);
+            hipMemcpyAsync(directions, dirDev, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st);
+            hipStreamSynchronize(st);
+            for (int32_t i = 0; i < n; ++i)
+            {
+                colors[i * 4 + 0] = res[(size_t)i].color[0]; colors[i * 4 + 1] = res[(size_t)i].color[1];
+                colors[i * 4 + 2] = res[(size_t)i].color[2]; colors[i * 4 + 3] = 0.0f;
+            }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error("trace_rays: device error"); rc = PIMGPU_E_DEVICE; }
+    }
+    cleanup();
+    return rc;
+}
+
+int pimgpu_trace_rays(PimScene* scene, const float* ro, const float* rd, int32_t n, uint32_t sampleIndex, uint32_t seed,
+    int32_t maxBounces, PimResult* out)
+{
+    if (n > 0 && (!ro || !rd || !out)) { set_error("trace_rays: NULL argument"); return PIMGPU_E_INVALID; }
+    return trace_rays_common(scene, ro, rd, nullptr, n, sampleIndex, seed, maxBounces, out, nullptr, nullptr);
+}
+
+int pimgpu_raygen(PimScene* scene, const float* origin, int32_t count, uint32_t sampleIndex, uint32_t seed, int32_t maxBounces,
+    float* colors, float* directions)
+{
+    if (count > 0 && (!origin || !colors || !directions)) { set_error("raygen: NULL argument"); return PIMGPU_E_INVALID; }
+    return trace_rays_common(scene, nullptr, nullptr, origin, count, sampleIndex, seed, maxBounces, nullptr, colors, directions);
+}
+
+} /* extern "C" */

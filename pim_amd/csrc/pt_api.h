@@ -1,0 +1,95 @@
+/*
+ * pt_api.h -- host objects behind the opaque handles of include/pimgpu.h.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include "pt_host.h"
+
+/* PtScene (rendering/path_tracer.c:122-166) resident in HBM */
+struct PimScene
+{
+    pt::DScene d = {};
+    /* owned device memory */
+    pt::v4* positions = nullptr; pt::v4* normals = nullptr; pt::v2* uvs = nullptr; int32_t* matIds = nullptr;
+    int32_t* vertToEmit = nullptr; int32_t* emitToVert = nullptr;
+    PimMaterial* materials = nullptr; pt::DTexture* textures = nullptr;
+    std::vector<void*> texels;
+    pt::v3* sky[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    pt::v2* lut = nullptr;
+    int32_t* cellLength = nullptr; float* pdf = nullptr; float* cdf = nullptr; uint32_t* live = nullptr;
+    uint32_t* cellSum = nullptr; float* cellIntegral = nullptr;
+    pt::BvhStorage bvh;
+    uint32_t seed = 0;
+    float metersPerCell = 1.5f;
+    float bvhBuildMs = 0.0f, setupMs = 0.0f;
+    int32_t bvhDepth = 0;
+};
+
+/* PtTrace (rendering/path_tracer.h:44-52): running-mean float3 images in HBM */
+struct PimTrace
+{
+    int32_t width = 0, height = 0;
+    float* color = nullptr; float* albedo = nullptr; float* normal = nullptr;
+    PimTraceStats stats = {};
+};
+
+namespace pt {
+
+/* per-path state of the wavefront integrator, SoA over path slots (DESIGN.md "path state") */
+struct PathState
+{
+    uint4* rng;          /* Prng stream */
+    float4* ro;          /* ray origin (w unused) */
+    float4* rd;          /* ray direction (w unused) */
+    float4* atten;       /* attenuation.xyz, resultWeight */
+    float4* lum;         /* luminance.xyz, w = bits: bounce | prevFlags<<16 */
+    float4* albedo;      /* albedo accumulator.xyz */
+    float4* normal;      /* normal accumulator.xyz */
+    float4* nee0;        /* between shade_a and shade_b: mode, iVert, selectPdf, distSq */
+    float4* nee1;        /* BRDF-branch sample: attenuation.xyz, pdf */
+};
+
+/* library-owned work buffers, grown on demand and reused by every call */
+struct WorkBuffers
+{
+    int64_t rayCap = 0, pathCap = 0;
+    float4* rayO = nullptr; float4* rayD = nullptr;           /* packed rays for the public intersect call */
+    /* integrator */
+    PathState ps = {};
+    float4* extO[2] = { nullptr, nullptr }; float4* extD[2] = { nullptr, nullptr };   /* extension rays, by queue position */
+    float4* neeO = nullptr; float4* neeD = nullptr;
+    DHit* extHit = nullptr; DHit* neeHit = nullptr;
+    int32_t* queue[2] = { nullptr, nullptr };
+    int32_t* counters = nullptr;        /* [0],[1]: queue lengths; device side */
+    unsigned long long* stats = nullptr;/* ext, shadow, other rays */
+    PimResult* results = nullptr;       /* per path slot */
+    int ensure_rays(int64_t n);
+    int ensure_paths(int64_t n);
+    void release();
+};
+
+struct Library
+{
+    bool initialised = false;
+    int device = 0;
+    int cuCount = 0;
+    hipStream_t stream = nullptr;
+    TraceResources trace;
+    WorkBuffers work;
+};
+extern Library g_lib;
+
+int check_ready();
+
+/* setup.hip */
+int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float* pdfsDev, hipStream_t stream);
+int setup_light_grid(const DScene& s, float metersPerCell, uint32_t seed, int32_t* cellLengthDev, uint32_t* statusDev, hipStream_t stream);
+int update_dists(const DScene& s, hipStream_t stream);
+
+/* integrate.hip */
+int pack_rays(const float4* ro, const float4* rd, const float* tNear, const float* tFar, int32_t n, float4* rayO, float4* rayD, hipStream_t stream);
+
+} /* namespace pt */
+
+#endif

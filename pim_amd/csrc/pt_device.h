@@ -1,0 +1,87 @@
+/*
+ * pt_device.h -- device-side scene description shared by every kernel of libpimgpu.
+ *
+ * DScene is the HBM-resident PtScene (rendering/path_tracer.c:122-166): the six flattened
+ * vertex arrays, the emissive maps, the light grid with its per-cell Dist1D arrays, materials,
+ * textures, sky cubemap, BRDF LUT, media description, plus the GPU acceleration structure that
+ * replaces Embree's RTCScene (path_tracer.c:618-690).  It is passed to kernels BY VALUE
+ * (a few hundred bytes of kernarg), so a kernel dereferences no descriptor in memory.
+ */
+#ifndef PT_DEVICE_H
+#define PT_DEVICE_H
+
+#include "pt_math.h"
+#include "../../include/pimgpu.h"
+
+namespace pt {
+
+/* build-defined RNG stream tags (the reference seeds per host thread from the clock;
+ * here every work item owns a stream seeded by Pcg4 of its coordinates and one of these tags) */
+#define PT_TAG_PIXEL    0x9E3779B9u
+#define PT_TAG_RAY      0x7261795Fu
+#define PT_TAG_BAKE     0x62616B65u
+#define PT_TAG_BAKE_PT  0xA511E9B3u
+#define PT_TAG_EMIT     0x454D4954u
+#define PT_TAG_GRID     0x47524944u
+
+struct DTexture { int32_t width, height, format, _pad; const uint32_t* texels; };
+
+/* PtMediaDesc with its derived fields, path_tracer.c:91-111,1963-1987 */
+struct DMedia
+{
+    v4 constantColor, noiseColor;
+    float constantMfp, noiseMfp;
+    v4 constantMu, noiseMu;
+    float rcpMajorant, absorption;
+    int32_t noiseOctaves;
+    float noiseGain, noiseLacunarity, noiseFreq, noiseScale, noiseHeight, noiseRange;
+    float phaseDirA, phaseDirB, phaseBlend;
+};
+
+/* Grid, math/grid.h:8-15 */
+struct DGrid { v4 lo, hi; int32_t sx, sy, sz; float cellsPerMeter; };
+
+/*
+ * Acceleration structure.  Wide BVH with 4 children per node ("BVH4"), 128 bytes per node so a
+ * node is exactly one 128-B cache line / one 8-lane x 16-B coalesced group:
+ *
+ *   float4 q[0] = (lo.x[0..3])   q[1] = (lo.y[0..3])   q[2] = (lo.z[0..3])
+ *   float4 q[3] = (hi.x[0..3])   q[4] = (hi.y[0..3])   q[5] = (hi.z[0..3])
+ *   int4   q[6] = child[0..3]    q[7] = unused
+ *
+ * child >= 0: inner node index; child < 0 and != PT_BVH_EMPTY: leaf, ~child = (first << 3) | (count - 1),
+ * first = index of the leaf's first triangle in tris[] (3 float4 per triangle, leaf order:
+ * p0.xyz + primID bits in w, p1.xyz, p2.xyz); empty slots have an inverted box and PT_BVH_EMPTY.
+ */
+#define PT_BVH_EMPTY  ((int32_t)0x80000000)
+#define PT_LEAF_MAX   4
+
+struct DBvh
+{
+    const float4* nodes;     /* 8 float4 per node */
+    const float4* tris;      /* 3 float4 per triangle, leaf order */
+    int32_t nodeCount;
+    int32_t triCount;
+};
+
+struct DScene
+{
+    int32_t vertCount, triCount, matCount, texCount, emissiveCount;
+    const v4* positions; const v4* normals; const v2* uvs; const int32_t* matIds;
+    const int32_t* vertToEmit; const int32_t* emitToVert;
+    const PimMaterial* materials;
+    const DTexture* textures;
+    int32_t skySize; const v3* sky[6];
+    int32_t lutSize; const v2* lut;
+    DMedia media;
+    DGrid grid; int32_t gridLen;
+    const int32_t* cellLength; float* pdf; float* cdf; uint32_t* live; uint32_t* cellSum; float* cellIntegral;
+    DBvh bvh;
+};
+
+/* raw closest-hit record, 16 bytes: primID (-1 = miss), t, u, v (u = weight of p1, v = weight of p2) */
+struct DHit { int32_t prim; float t, u, v; };
+
+} /* namespace pt */
+
+#endif

@@ -1,0 +1,55 @@
+/*
+ * pt_host.h -- host-side declarations internal to libpimgpu (not part of the C-ABI).
+ */
+#ifndef PT_HOST_H
+#define PT_HOST_H
+
+#include "pt_device.h"
+#include <string>
+#include <vector>
+
+namespace pt {
+
+/* device memory of the acceleration structure + the build's scratch (kept for rebuilds) */
+struct BvhStorage
+{
+    float4* nodes = nullptr;
+    float4* tris = nullptr;
+    void* scratch = nullptr;
+    size_t scratchBytes = 0;
+    int32_t capacityTris = 0;
+    int32_t triCount = 0;
+    int32_t nodeCount = 0;
+    int32_t* maxDepthDev = nullptr;     /* inside scratch: depth of the binary tree of the last build */
+    void release();
+    DBvh view() const { DBvh b; b.nodes = nodes; b.tris = tris; b.nodeCount = nodeCount; b.triCount = triCount; return b; }
+};
+
+/* bvh_build.hip: full (re)build from device positions (float4[3*triCount]); asynchronous on stream */
+int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream_t stream);
+
+/* per-process traversal resources: overflow area of the per-lane traversal stacks */
+struct TraceResources
+{
+    uint2* spill = nullptr;
+    uint32_t* status = nullptr;          /* device word: bit 0 = traversal stack overflow */
+    int32_t gridBlocks = 0;
+    int ensure();
+    void release();
+};
+
+/* trace.hip */
+int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
+    int32_t n, const int32_t* countDev, hipStream_t stream);
+int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, int32_t* occluded,
+    int32_t n, hipStream_t stream);
+int make_rayhits(const DScene& scene, const float4* rayD, const DHit* hits, PimRayHit* out, int32_t n, hipStream_t stream);
+
+void set_error(const char* fmt, ...);
+
+#define PT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    pt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return PIMGPU_E_DEVICE; } } while (0)
+
+} /* namespace pt */
+
+#endif

@@ -1,0 +1,232 @@
+/*
+ * traverse.h -- per-lane BVH4 traversal with a watertight ray/triangle test; replaces
+ * rtcIntersect1 / rtcOccluded (rendering/path_tracer.c:470-553).
+ *
+ * Contract (the same one the CPU checker states):
+ *   - closest hit over t in (tNear, tFar]; two sided; among equal t the LOWEST primID wins, so
+ *     the answer does not depend on traversal order or on the shape of the tree;
+ *   - the triangle test is Woop/Benthin/Wald 2013 "watertight" in fp32 with the fp64 edge-function
+ *     fallback, written without FMA contraction so the host evaluates the same bits;
+ *   - u = weight of p1, v = weight of p2 (Embree's convention, RTC_GEOMETRY_TYPE_TRIANGLE).
+ *
+ * Stack: entries are (entry distance, child).  The first PT_STACK_LDS entries of a lane live in LDS
+ * (lane-interleaved, conflict free), deeper ones in a global spill area; TrivialStack keeps all of
+ * them in per-lane scratch for the rare rays that shading code traces inline.
+ */
+#ifndef PT_TRAVERSE_H
+#define PT_TRAVERSE_H
+
+#include "pt_device.h"
+
+namespace pt {
+
+#define PT_STACK_LDS    8
+#define PT_STACK_SPILL  56
+#define PT_STACK_MAX    (PT_STACK_LDS + PT_STACK_SPILL)
+
+struct RayPre
+{
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+    float ox, oy, oz;
+};
+
+__device__ __forceinline__ float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+__device__ __forceinline__ RayPre ray_pre(float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    RayPre r;
+    int kz = 0;
+    float dmax = dx;
+    if (fabsf(dy) > fabsf(dmax)) { kz = 1; dmax = dy; }
+    if (fabsf(dz) > fabsf(dmax)) { kz = 2; dmax = dz; }
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    if (dmax < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = sel3(dx, dy, dz, kx) / dmax;
+    r.Sy = sel3(dx, dy, dz, ky) / dmax;
+    r.Sz = 1.0f / dmax;
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    return r;
+}
+
+/* true and t,u,v written when the triangle is hit inside (tNear, tFar] */
+__device__ __forceinline__ bool tri_test(const RayPre& r, float4 p0, float4 p1, float4 p2, float tNear, float tFar,
+    float* tOut, float* uOut, float* vOut)
+{
+    const float a0 = p0.x - r.ox, a1 = p0.y - r.oy, a2 = p0.z - r.oz;
+    const float b0 = p1.x - r.ox, b1 = p1.y - r.oy, b2 = p1.z - r.oz;
+    const float c0 = p2.x - r.ox, c1 = p2.y - r.oy, c2 = p2.z - r.oz;
+    const float akx = sel3(a0, a1, a2, r.kx), aky = sel3(a0, a1, a2, r.ky), akz = sel3(a0, a1, a2, r.kz);
+    const float bkx = sel3(b0, b1, b2, r.kx), bky = sel3(b0, b1, b2, r.ky), bkz = sel3(b0, b1, b2, r.kz);
+    const float ckx = sel3(c0, c1, c2, r.kx), cky = sel3(c0, c1, c2, r.ky), ckz = sel3(c0, c1, c2, r.kz);
+    const float Ax = akx - r.Sx * akz, Ay = aky - r.Sy * akz;
+    const float Bx = bkx - r.Sx * bkz, By = bky - r.Sy * bkz;
+    const float Cx = ckx - r.Sx * ckz, Cy = cky - r.Sy * ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    {
+        const double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        const double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        const double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * akz, Bz = r.Sz * bkz, Cz = r.Sz * ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float t = T / det;
+    if (!(t > tNear && t <= tFar)) return false;
+    *tOut = t;
+    *uOut = V / det;
+    *vOut = W / det;
+    return true;
+}
+
+__device__ __forceinline__ void hit_consider(DHit& h, int32_t prim, float t, float u, float v)
+{
+    if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim)))
+    {
+        h.prim = prim; h.t = t; h.u = u; h.v = v;
+    }
+}
+
+/* ---- stacks ---- */
+
+struct TrivialStack
+{
+    uint2 e[PT_STACK_MAX];
+    int sp;
+    __device__ __forceinline__ void init() { sp = 0; }
+    __device__ __forceinline__ bool push(float t, int32_t c)
+    {
+        if (sp >= PT_STACK_MAX) return false;
+        e[sp++] = make_uint2(__float_as_uint(t), (uint32_t)c);
+        return true;
+    }
+    __device__ __forceinline__ bool pop(float* t, int32_t* c)
+    {
+        if (sp == 0) return false;
+        const uint2 v = e[--sp];
+        *t = __uint_as_float(v.x); *c = (int32_t)v.y;
+        return true;
+    }
+};
+
+struct LdsStack
+{
+    uint2* lds;         /* &shared[threadIdx.x], stride ldsStride */
+    uint2* spill;       /* &spill[global lane slot], stride spillStride */
+    int ldsStride;
+    int64_t spillStride;
+    int sp;
+    __device__ __forceinline__ void init() { sp = 0; }
+    __device__ __forceinline__ bool push(float t, int32_t c)
+    {
+        if (sp >= PT_STACK_MAX) return false;
+        const uint2 v = make_uint2(__float_as_uint(t), (uint32_t)c);
+        if (sp < PT_STACK_LDS) lds[sp * ldsStride] = v;
+        else spill[(int64_t)(sp - PT_STACK_LDS) * spillStride] = v;
+        ++sp;
+        return true;
+    }
+    __device__ __forceinline__ bool pop(float* t, int32_t* c)
+    {
+        if (sp == 0) return false;
+        --sp;
+        const uint2 v = (sp < PT_STACK_LDS) ? lds[sp * ldsStride] : spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
+        *t = __uint_as_float(v.x); *c = (int32_t)v.y;
+        return true;
+    }
+};
+
+#define PT_SWAP_IF(da, ca, db, cb) { const bool s_ = (db) < (da); const float td_ = s_ ? (db) : (da); const float tD_ = s_ ? (da) : (db); \
+    const int32_t tc_ = s_ ? (cb) : (ca); const int32_t tC_ = s_ ? (ca) : (cb); (da) = td_; (db) = tD_; (ca) = tc_; (cb) = tC_; }
+
+/*
+ * ANY = false: closest hit (see contract above).  ANY = true: returns at the first accepted hit.
+ * overflow: set to true when the stack was full and a subtree had to be dropped (the caller reports it).
+ */
+template <bool ANY, class Stack>
+__device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, float oz, float dx, float dy, float dz,
+    float tNear, float tFar, Stack& st, bool& overflow)
+{
+    DHit h; h.prim = -1; h.t = tFar; h.u = 0.0f; h.v = 0.0f;
+    if (!(tFar > tNear)) return h;
+    const RayPre r = ray_pre(ox, oy, oz, dx, dy, dz);
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    st.init();
+    int32_t cur = 0;
+    const float4* __restrict__ nodes = bvh.nodes;
+    const float4* __restrict__ tris = bvh.tris;
+    for (;;)
+    {
+        if (cur >= 0)
+        {
+            const float4* q = nodes + (size_t)cur * 8;
+            const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+            const float4 ch = q[6];
+            float d[4]; int32_t c[4];
+            c[0] = __float_as_int(ch.x); c[1] = __float_as_int(ch.y); c[2] = __float_as_int(ch.z); c[3] = __float_as_int(ch.w);
+            const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+            const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const float ax = (lx[k] - ox) * ix, bx = (hx[k] - ox) * ix;
+                const float ay = (ly[k] - oy) * iy, by = (hy[k] - oy) * iy;
+                const float az = (lz[k] - oz) * iz, bz = (hz[k] - oz) * iz;
+                float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
+                float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
+                t1 = fminf(t1, h.t);
+                d[k] = (t0 <= t1) ? t0 : __builtin_inff();
+            }
+            /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
+            PT_SWAP_IF(d[0], c[0], d[1], c[1]);
+            PT_SWAP_IF(d[2], c[2], d[3], c[3]);
+            PT_SWAP_IF(d[0], c[0], d[2], c[2]);
+            PT_SWAP_IF(d[1], c[1], d[3], c[3]);
+            PT_SWAP_IF(d[1], c[1], d[2], c[2]);
+            if (d[3] < __builtin_inff()) overflow |= !st.push(d[3], c[3]);
+            if (d[2] < __builtin_inff()) overflow |= !st.push(d[2], c[2]);
+            if (d[1] < __builtin_inff()) overflow |= !st.push(d[1], c[1]);
+            if (d[0] < __builtin_inff()) { cur = c[0]; continue; }
+        }
+        else
+        {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; ++k)
+            {
+                const float4* tp = tris + (size_t)(first + k) * 3;
+                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                float t, u, v;
+                if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v))
+                {
+                    hit_consider(h, __float_as_int(p0.w), t, u, v);
+                    if (ANY) return h;
+                }
+            }
+        }
+        /* pop, culling entries that start beyond the current closest hit */
+        float t; int32_t c;
+        bool got = false;
+        while (st.pop(&t, &c))
+        {
+            if (t <= h.t) { got = true; break; }
+        }
+        if (!got) break;
+        cur = c;
+    }
+    return h;
+}
+
+} /* namespace pt */
+
+#endif

@@ -1,0 +1,101 @@
+"""CPU tests of the oracle on whole scenes (no GPU): its three intersectors agree, the scene set-up is
+what the Cornell recipe predicts, the two libm variants give statistically equal images, and the
+harness' float32 flatten matches the oracle's restatement of FlattenDrawables."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from pim_amd import scenes
+from tests.util import OracleScene, load_oracle, copy_dof, bits
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return scenes.cornell_box()
+
+
+def test_cornell_recipe_counts(cornell):
+    # 9 boxes x 12 = 108 triangles, 12 emissive (the light box), 7^3 grid cells at 1.5 m
+    assert cornell.tri_count == 108
+    o = OracleScene(cornell.desc, accel=1)
+    info = o.info()
+    assert info.emissiveCount == 12
+    assert list(info.gridSize) == [7, 7, 7] and info.gridLen == 343
+    lights = o.download_lights()
+    assert (lights["emitToVert"] == np.arange(12) * 3 + 2 * 36).all()       # third entity = Cornell_Light
+    assert (lights["vertToEmit"] >= 0).sum() == 36
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_intersectors_agree(cornell, accel):
+    """fp32 watertight brute force == fp32 BVH bit for bit; both agree with the fp64 ground truth on the
+    primitive for >= 99.99% of rays and on t to 1e-5 relative (BASELINE.json's gate)"""
+    o = OracleScene(cornell.desc, accel=accel)
+    ro, rd = scenes.random_rays(cornell, 50000, seed=3)
+    p_a, tuv_a = o.intersect_raw(ro, rd)
+    p_b, tuv_b = o.intersect_raw(ro, rd, brute=True)
+    assert (p_a == p_b).all() and (bits(tuv_a) == bits(tuv_b)).all()
+    p64, t64 = o.intersect_f64(ro, rd)
+    assert (p_a == p64).mean() >= 0.9999
+    same = (p_a == p64) & (p64 >= 0)
+    # 1e-5 relative, plus 4 ulp of the largest coordinate (5 m) for hits a few mm from the origin, where the
+    # fp32 vertex data itself limits t to an ABSOLUTE accuracy
+    assert (np.abs(tuv_a[same, 0] - t64[same]) <= 1e-5 * t64[same] + 2e-6).all()
+
+
+def test_synthetic_scene_bvh_equals_brute_force():
+    sc = scenes.synthetic_scene(target_tris=6000, seed=5, extent=20.0, emissive_attempts=16)
+    o = OracleScene(sc.desc, accel=1)
+    ro, rd = scenes.random_rays(sc, 4000, seed=9)
+    p_a, tuv_a = o.intersect_raw(ro, rd)
+    p_b, tuv_b = o.intersect_raw(ro, rd, brute=True)
+    assert (p_a == p_b).all() and (bits(tuv_a) == bits(tuv_b)).all()
+
+
+def test_flatten_matches_oracle_restatement():
+    lib = load_oracle()
+    rng = np.random.default_rng(2)
+    for mesh in (scenes.box_mesh(), scenes.sphere_mesh(6)):
+        t = rng.uniform(-3, 3, 3).astype(np.float32)
+        q = scenes.quat_lookat(scenes.normalize3(rng.normal(size=3).astype(np.float32)), np.array([0, 1, 0], np.float32))
+        s = rng.uniform(0.5, 2, 3).astype(np.float32)
+        P, N, U = scenes.flatten_entity(t, q, s, mesh)
+        n = mesh[0].shape[0]
+        mp = np.zeros((n, 4), np.float32); mp[:, :3] = mesh[0]; mp[:, 3] = 1
+        mn = np.zeros((n, 4), np.float32); mn[:, :3] = mesh[1]
+        mu = np.zeros((n, 4), np.float32); mu[:, :2] = mesh[2]
+        oP, oN, oU = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros((n, 2), np.float32)
+        t4 = np.zeros(4, np.float32); t4[:3] = t
+        s4 = np.zeros(4, np.float32); s4[:3] = s
+        lib.orc_flatten_entity(t4.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p), s4.ctypes.data_as(ctypes.c_void_p),
+                               mp.ctypes.data_as(ctypes.c_void_p), mn.ctypes.data_as(ctypes.c_void_p), mu.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.c_int32(n), oP.ctypes.data_as(ctypes.c_void_p), oN.ctypes.data_as(ctypes.c_void_p), oU.ctypes.data_as(ctypes.c_void_p))
+        assert np.allclose(P, oP, rtol=0, atol=2e-6) and np.allclose(N[:, :3], oN[:, :3], rtol=0, atol=2e-6) and (U == oU).all()
+
+
+def test_libm_variants_agree_statistically(cornell):
+    """liborc.so (glibc libm, bit-exact to the reference headers) and liborc_p.so (portable libm, what the
+    GPU is compared with) render the same image up to the few paths a last-ulp difference sends elsewhere"""
+    W, H = 96, 54
+    res = []
+    for portable in (False, True):
+        o = OracleScene(cornell.desc, accel=1, portable=portable)
+        img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+        dof = scenes.default_dof()
+        for s in range(8):
+            o.trace_image(img, W, H, scenes.pt_test_camera(), dof, scenes.trace_params(s, max_bounces=4))
+        res.append((img[0].copy(), o.stddev(img[0], W, H)))
+    (a, (ma, sa)), (b, (mb, sb)) = res
+    close = np.isclose(a, b, rtol=1e-3, atol=1e-5).all(axis=1).mean()
+    assert close > 0.97, close
+    assert abs(ma - mb) <= 0.02 * ma and abs(sa - sb) <= 0.1 * sa
+
+
+def test_stddev_is_the_reference_formula(cornell):
+    o = OracleScene(cornell.desc, accel=0)
+    rng = np.random.default_rng(1)
+    c = rng.uniform(0, 2, (40 * 30, 3)).astype(np.float32)
+    m, s = o.stddev(c, 40, 30)
+    lum = c.astype(np.float64).sum(1) / 3
+    assert abs(m - lum.mean()) < 1e-4 and abs(s - lum.std(ddof=1)) < 1e-4

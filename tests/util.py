@@ -20,3 +20,134 @@ def load_oracle(portable=False):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         _ORACLE[name] = ctypes.CDLL(path)
     return _ORACLE[name]
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes face of oracle/pim_oracle.h (TEST INFRASTRUCTURE ONLY)
+
+import numpy as np  # noqa: E402
+
+from pim_amd import api  # noqa: E402
+
+C = ctypes
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleScene:
+    """orc_scene_create .. orc_scene_destroy; accel 0 = brute force, 1 = binned-SAH BVH2"""
+
+    def __init__(self, desc, accel=1, threads=8, portable=True):
+        self.lib = load_oracle(portable)
+        self.lib.orc_scene_create.restype = C.c_void_p
+        self.threads = threads
+        self.handle = C.c_void_p(self.lib.orc_scene_create(C.byref(desc), C.c_int(accel), C.c_int(threads)))
+        assert self.handle, "orc_scene_create failed"
+
+    def close(self):
+        if self.handle:
+            self.lib.orc_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        out = api.PimSceneInfo()
+        self.lib.orc_scene_info(self.handle, C.byref(out))
+        return out
+
+    def download_lights(self):
+        info = self.info()
+        E, L, V = info.emissiveCount, info.gridLen, info.vertCount
+        out = dict(vertToEmit=np.zeros(V, np.int32), emitToVert=np.zeros(E, np.int32), cellLength=np.zeros(L, np.int32),
+                   pdf=np.zeros(L * E, np.float32), cdf=np.zeros(L * (E + 1), np.float32), live=np.zeros(L * E, np.uint32))
+        self.lib.orc_scene_download_lights(self.handle, _p(out["vertToEmit"]), _p(out["emitToVert"]), _p(out["cellLength"]),
+                                           _p(out["pdf"]), _p(out["cdf"]), _p(out["live"]))
+        return out
+
+    def update_dists(self):
+        self.lib.orc_scene_update_dists(self.handle)
+
+    def intersect(self, ro, rd, tNear=None, tFar=None):
+        ro, rd = api.f32(ro), api.f32(rd)
+        n = ro.shape[0]
+        tn = api.f32(tNear) if tNear is not None else np.zeros(n, np.float32)
+        tf = api.f32(tFar) if tFar is not None else np.full(n, api.RCP_EPSILON, np.float32)
+        out = np.zeros(n, api.RAYHIT_DTYPE)
+        self.lib.orc_intersect(self.handle, _p(ro), _p(rd), _p(tn), _p(tf), C.c_int32(n), _p(out), C.c_int(self.threads))
+        return out
+
+    def intersect_raw(self, ro, rd, tNear=None, tFar=None, brute=False):
+        ro, rd = api.f32(ro), api.f32(rd)
+        n = ro.shape[0]
+        tn = api.f32(tNear) if tNear is not None else np.zeros(n, np.float32)
+        tf = api.f32(tFar) if tFar is not None else np.full(n, api.RCP_EPSILON, np.float32)
+        prim = np.zeros(n, np.int32)
+        tuv = np.zeros((n, 3), np.float32)
+        self.lib.orc_intersect_raw(self.handle, _p(ro), _p(rd), _p(tn), _p(tf), C.c_int32(n), _p(prim), _p(tuv),
+                                   C.c_int(1 if brute else 0), C.c_int(self.threads))
+        return prim, tuv
+
+    def intersect_f64(self, ro, rd, tNear=None, tFar=None):
+        ro, rd = api.f32(ro), api.f32(rd)
+        n = ro.shape[0]
+        tn = api.f32(tNear) if tNear is not None else np.zeros(n, np.float32)
+        tf = api.f32(tFar) if tFar is not None else np.full(n, api.RCP_EPSILON, np.float32)
+        prim = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float64)
+        self.lib.orc_intersect_f64(self.handle, _p(ro), _p(rd), _p(tn), _p(tf), C.c_int32(n), _p(prim), _p(t), C.c_int(self.threads))
+        return prim, t
+
+    def trace_rays(self, ro, rd, sampleIndex=0, seed=0, maxBounces=0):
+        ro, rd = api.f32(ro), api.f32(rd)
+        n = ro.shape[0]
+        out = np.zeros(n, api.RESULT_DTYPE)
+        self.lib.orc_trace_rays(self.handle, _p(ro), _p(rd), C.c_int32(n), C.c_uint32(sampleIndex), C.c_uint32(seed),
+                                C.c_int32(maxBounces), _p(out), C.c_int(self.threads))
+        return out
+
+    def raygen(self, origin, count, sampleIndex=0, seed=0, maxBounces=0):
+        origin = api.f32(origin)
+        colors = np.zeros((count, 4), np.float32)
+        directions = np.zeros((count, 4), np.float32)
+        self.lib.orc_raygen(self.handle, _p(origin), C.c_int32(count), C.c_uint32(sampleIndex), C.c_uint32(seed),
+                            C.c_int32(maxBounces), _p(colors), _p(directions), C.c_int(self.threads))
+        return colors, directions
+
+    def trace_image(self, images, width, height, camera, dof, params):
+        """images = (color, albedo, normal) float32 (n,3) arrays updated in place (running mean); returns stats"""
+        stats = api.PimTraceStats()
+        self.lib.orc_trace_image(self.handle, _p(images[0]), _p(images[1]), _p(images[2]), C.c_int32(width), C.c_int32(height),
+                                 C.byref(camera), C.byref(dof), C.byref(params), C.c_int(self.threads), C.byref(stats))
+        return stats
+
+    def stddev(self, color, width, height):
+        m, s = C.c_float(), C.c_float()
+        self.lib.orc_stddev(_p(api.f32(color)), C.c_int32(width), C.c_int32(height), C.byref(m), C.byref(s))
+        return m.value, s.value
+
+    def lightmap_bake(self, pages, lmSize, texelsPerMeter, timeSlice, spp, passIndex=0, seed=0, maxBounces=0,
+                      texelBegin=0, texelEnd=-1):
+        arr = (api.PimLightmapPage * len(pages))()
+        for i, p in enumerate(pages):
+            arr[i].block = p.ctypes.data
+        self.lib.orc_lightmap_bake(self.handle, arr, C.c_int32(len(pages)), C.c_int32(lmSize), C.c_float(texelsPerMeter),
+                                   C.c_float(timeSlice), C.c_int32(spp), C.c_uint32(passIndex), C.c_uint32(seed),
+                                   C.c_int32(maxBounces), C.c_int64(texelBegin), C.c_int64(texelEnd), C.c_int(self.threads))
+
+
+def copy_dof(d):
+    out = api.PimDofInfo()
+    C.memmove(C.byref(out), C.byref(d), C.sizeof(d))
+    return out
+
+
+def bits(a):
+    """float32 array -> uint32 view for bit-exact comparisons"""
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
