@@ -468,6 +468,11 @@ static void grid_new(OrcGrid* g, v4 lo, v4 hi, float cellsPerMeter)
     v4 sizef = o4_ceil(o4_muls(range, cellsPerMeter));
     g->lo = lo; g->hi = hi;
     g->sx = (int32_t)sizef.x; g->sy = (int32_t)sizef.y; g->sz = (int32_t)sizef.z;
+    /* BUILD-DEFINED: a scene flat along an axis would get a zero-sized grid, which the reference indexes out of
+     * bounds; keep at least one cell per axis (same rule in the HIP path) */
+    if (g->sx < 1) g->sx = 1;
+    if (g->sy < 1) g->sy = 1;
+    if (g->sz < 1) g->sz = 1;
     g->cellsPerMeter = cellsPerMeter;
 }
 static v4 grid_position(const OrcGrid* g, int32_t index)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 namespace pt {
 
@@ -36,7 +37,7 @@ static int upload(T** dst, const void* src, size_t count)
     const size_t bytes = sizeof(T) * (count ? count : 1);
     if (hipMalloc((void**)dst, bytes) != hipSuccess) { set_error("hipMalloc of %zu bytes failed", bytes); return PIMGPU_E_NOMEM; }
     if (count && src) PT_HIP(hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice));
-    else PT_HIP(hipMemset(*dst, 0, bytes));
+    else PT_HIP(hipMemsetAsync(*dst, 0, bytes, g_lib.stream));   /* ordered with the kernels (the stream is non-blocking) */
     return PIMGPU_OK;
 }
 
@@ -103,6 +104,11 @@ static int scene_build_bvh(PimScene* s)
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (rc) { if (rc == PIMGPU_E_NOMEM) set_error("out of device memory building the BVH"); return rc; }
     s->d.bvh = s->bvh.view();
+    if (getenv("PIMGPU_VALIDATE_BVH"))
+    {
+        std::string why;
+        if ((rc = bvh_validate(&s->bvh, g_lib.stream, &why))) { set_error("BVH validation failed: %s", why.c_str()); return rc; }
+    }
     if (s->bvh.maxDepthDev) PT_HIP(hipMemcpy(&s->bvhDepth, s->bvh.maxDepthDev, 4, hipMemcpyDeviceToHost));
     return PIMGPU_OK;
 }
@@ -261,6 +267,9 @@ int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
             const float cellsPerMeter = 1.0f / s->metersPerCell;
             const v4 sizef = f4_ceil(f4_muls(f4_sub(hi, lo), cellsPerMeter));
             g.lo = lo; g.hi = hi; g.sx = (int32_t)sizef.x; g.sy = (int32_t)sizef.y; g.sz = (int32_t)sizef.z; g.cellsPerMeter = cellsPerMeter;
+            /* a scene flat along an axis gives Grid_New a zero extent (math/grid.h:17-25), which the reference then
+             * indexes out of bounds; keep at least one cell per axis */
+            g.sx = g.sx < 1 ? 1 : g.sx; g.sy = g.sy < 1 ? 1 : g.sy; g.sz = g.sz < 1 ? 1 : g.sz;
             const int64_t len = (int64_t)g.sx * g.sy * g.sz;
             if (len <= 0 || len > (1ll << 30)) { set_error("scene_create: light grid of %lld cells", (long long)len); return fail(PIMGPU_E_LIMIT); }
             s->d.grid = g; s->d.gridLen = (int32_t)len;

@@ -492,4 +492,47 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
 }
 
+/* debugging aid (PIMGPU_VALIDATE_BVH=1): walk the tree on the host and check that every child index,
+ * leaf range and box is sane and that every triangle is referenced exactly once */
+int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why)
+{
+    hipStreamSynchronize(stream);
+    const int32_t n = b->triCount;
+    const size_t nodeCap = (size_t)(n > 1 ? n - 1 : 1);
+    std::vector<float4> nodes(nodeCap * 8), tris((size_t)(n > 0 ? n : 1) * 3);
+    if (hipMemcpy(nodes.data(), b->nodes, sizeof(float4) * nodes.size(), hipMemcpyDeviceToHost) != hipSuccess) { *why = "copy of nodes failed"; return PIMGPU_E_DEVICE; }
+    if (n > 0 && hipMemcpy(tris.data(), b->tris, sizeof(float4) * (size_t)n * 3, hipMemcpyDeviceToHost) != hipSuccess) { *why = "copy of tris failed"; return PIMGPU_E_DEVICE; }
+    std::vector<uint8_t> seenTri((size_t)(n > 0 ? n : 1), 0), seenNode(nodeCap, 0), seenPrim((size_t)(n > 0 ? n : 1), 0);
+    std::vector<int32_t> stack; stack.push_back(0);
+    char buf[256];
+    size_t visited = 0;
+    while (!stack.empty())
+    {
+        const int32_t cur = stack.back(); stack.pop_back();
+        if (cur < 0 || (size_t)cur >= nodeCap) { snprintf(buf, sizeof(buf), "node index %d out of range [0,%zu)", cur, nodeCap); *why = buf; return PIMGPU_E_STATE; }
+        if (seenNode[(size_t)cur]) { snprintf(buf, sizeof(buf), "node %d reached twice", cur); *why = buf; return PIMGPU_E_STATE; }
+        seenNode[(size_t)cur] = 1; ++visited;
+        const float4* q = &nodes[(size_t)cur * 8];
+        const float ch[4] = { q[6].x, q[6].y, q[6].z, q[6].w };
+        for (int k = 0; k < 4; ++k)
+        {
+            int32_t c; __builtin_memcpy(&c, &ch[k], 4);
+            if (c == PT_BVH_EMPTY) continue;
+            if (c >= 0) { stack.push_back(c); continue; }
+            const uint32_t code = (uint32_t)~c, first = code >> 3, cnt = (code & 7u) + 1u;
+            if (cnt > PT_LEAF_MAX || (int64_t)first + cnt > n) { snprintf(buf, sizeof(buf), "node %d slot %d: leaf [%u,+%u) out of range (n=%d)", cur, k, first, cnt, n); *why = buf; return PIMGPU_E_STATE; }
+            for (uint32_t t = first; t < first + cnt; ++t)
+            {
+                if (seenTri[t]) { snprintf(buf, sizeof(buf), "triangle slot %u referenced twice", t); *why = buf; return PIMGPU_E_STATE; }
+                seenTri[t] = 1;
+                uint32_t prim; __builtin_memcpy(&prim, &tris[(size_t)t * 3].w, 4);
+                if (prim >= (uint32_t)n || seenPrim[prim]) { snprintf(buf, sizeof(buf), "triangle slot %u holds primID %u (bad or duplicate)", t, prim); *why = buf; return PIMGPU_E_STATE; }
+                seenPrim[prim] = 1;
+            }
+        }
+    }
+    for (int32_t t = 0; t < n; ++t) if (!seenTri[(size_t)t]) { snprintf(buf, sizeof(buf), "triangle slot %d is not referenced by any leaf (%zu nodes visited)", t, visited); *why = buf; return PIMGPU_E_STATE; }
+    return PIMGPU_OK;
+}
+
 } /* namespace pt */

@@ -28,6 +28,8 @@ struct BvhStorage
 /* bvh_build.hip: full (re)build from device positions (float4[3*triCount]); asynchronous on stream */
 int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream_t stream);
 
+int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why);
+
 /* per-process traversal resources: overflow area of the per-lane traversal stacks */
 struct TraceResources
 {

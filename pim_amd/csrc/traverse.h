@@ -185,7 +185,8 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
                 float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
                 float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
                 t1 = fminf(t1, h.t);
-                d[k] = (t0 <= t1) ? t0 : __builtin_inff();
+                /* empty slots carry an inverted box, which the min/max slab test would read as infinite: test the tag */
+                d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
             }
             /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
             PT_SWAP_IF(d[0], c[0], d[1], c[1]);
