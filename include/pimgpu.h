@@ -207,6 +207,11 @@ int pimgpu_shutdown(void);
 const char* pimgpu_last_error(void);
 /* the hipStream_t every call of the library runs on (for HIP events around a call: bench.py's roofline leg) */
 void* pimgpu_stream(void);
+/* measurement aid (no counterpart in the reference): with enable != 0 every closest-hit launch runs the COUNTING
+ * build of the traversal kernel, which adds up the BVH nodes it fetches (128 B each), the triangles it tests (48 B
+ * each) and the rays it traces.  out (may be NULL) receives {nodes, triangles, rays} counted since the last call;
+ * the counters are then cleared.  These are the per-ray figures of the roofline's algorithmic bytes. */
+int pimgpu_work_counters(int enable, uint64_t* out);
 
 /* ---- scene --------------------------------------------------------------- */
 
@@ -272,6 +277,9 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* trace, const PimCamera* camera
 int pimgpu_trace_download(const PimTrace* trace, float* color, float* albedo, float* normal);
 /* device addresses of the float3 buffers (for torch.distributed reduce without a host copy) */
 int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDev, void** normalDev);
+/* the same buffers copied device-to-device into caller-owned HBM (any pointer may be NULL): what a multi-GPU
+ * caller hands to an RCCL reduce */
+int pimgpu_trace_copy_dev(const PimTrace* trace, void* colorDst, void* albedoDst, void* normalDst);
 /* CalcStdDev (render_system.c:1374-1394) on the device colour buffer */
 int pimgpu_trace_stddev(const PimTrace* trace, float* meanOut, float* stddevOut);
 /* statistics of the last pimgpu_trace_image call: rays traced (extension, shadow, other), bounces */

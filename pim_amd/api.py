@@ -94,7 +94,7 @@ EXPORTS = [
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
-    "pimgpu_lightmap_bake", "pimgpu_stream",
+    "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
 ]
 
 _LIB = None
@@ -247,6 +247,10 @@ class Trace:
         check(self.lib.pimgpu_trace_buffers(self.handle, C.byref(c), C.byref(a), C.byref(n)), "pimgpu_trace_buffers")
         return c.value, a.value, n.value
 
+    def copy_dev(self, color_ptr, albedo_ptr=None, normal_ptr=None):
+        """device-to-device copy of the running-mean images into caller-owned HBM (e.g. torch tensors)"""
+        check(self.lib.pimgpu_trace_copy_dev(self.handle, C.c_void_p(color_ptr), C.c_void_p(albedo_ptr), C.c_void_p(normal_ptr)), "pimgpu_trace_copy_dev")
+
     def stddev(self):
         m, s = C.c_float(), C.c_float()
         check(self.lib.pimgpu_trace_stddev(self.handle, C.byref(m), C.byref(s)), "pimgpu_trace_stddev")
@@ -256,6 +260,13 @@ class Trace:
         out = PimTraceStats()
         check(self.lib.pimgpu_trace_stats(self.handle, C.byref(out)), "pimgpu_trace_stats")
         return out
+
+
+def work_counters(enable):
+    """switch the counting build of the traversal kernel on/off; returns (nodes, triangles, rays) since the last call"""
+    out = (C.c_uint64 * 3)()
+    check(load_library().pimgpu_work_counters(C.c_int(1 if enable else 0), out), "pimgpu_work_counters")
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def init(device=0):

@@ -744,6 +744,18 @@ int pimgpu_trace_download(const PimTrace* t, float* color, float* albedo, float*
     return PIMGPU_OK;
 }
 
+int pimgpu_trace_copy_dev(const PimTrace* t, void* colorDst, void* albedoDst, void* normalDst)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!t) { set_error("trace_copy_dev: NULL trace"); return PIMGPU_E_INVALID; }
+    const size_t bytes = sizeof(float) * 3 * (size_t)t->width * t->height;
+    if (colorDst) PT_HIP(hipMemcpyAsync(colorDst, t->color, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    if (albedoDst) PT_HIP(hipMemcpyAsync(albedoDst, t->albedo, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    if (normalDst) PT_HIP(hipMemcpyAsync(normalDst, t->normal, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
 int pimgpu_trace_buffers(const PimTrace* t, void** colorDev, void** albedoDev, void** normalDev)
 {
     if (!t) { set_error("trace_buffers: NULL trace"); return PIMGPU_E_INVALID; }

@@ -35,6 +35,8 @@ struct TraceResources
 {
     uint2* spill = nullptr;
     uint32_t* status = nullptr;          /* device word: bit 0 = traversal stack overflow */
+    unsigned long long* work = nullptr;  /* device: nodes fetched, triangles tested, rays (counting build of the kernel) */
+    bool counting = false;               /* pimgpu_work_counters(1, ..): launch the counting build */
     int32_t gridBlocks = 0;
     int ensure();
     void release();

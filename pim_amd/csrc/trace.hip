@@ -26,6 +26,7 @@ int TraceResources::ensure()
     PT_HIP(hipMalloc(&spill, sizeof(uint2) * lanes * PT_STACK_SPILL));
     PT_HIP(hipMalloc(&status, 256));
     PT_HIP(hipMemset(status, 0, 256));
+    work = (unsigned long long*)(status + 32);       /* bytes 128..: nodes, tris, rays of the counting build */
     return PIMGPU_OK;
 }
 
@@ -35,10 +36,10 @@ void TraceResources::release()
     spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
-template <bool ANY>
+template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
-    uint2* __restrict__ spill, uint32_t* __restrict__ status)
+    uint2* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work)
 {
     __shared__ uint2 sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
@@ -47,14 +48,24 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     st.spillStride = (int64_t)gridDim.x * kTraceThreads;
     st.spill = spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x);
     bool overflow = false;
+    TraverseCounts tc; tc.nodes = 0; tc.tris = 0;
+    uint32_t rays = 0;
     for (int32_t i = blockIdx.x * kTraceThreads + threadIdx.x; i < n; i += gridDim.x * kTraceThreads)
     {
         const float4 o = rayO[i], d = rayD[i];
-        const DHit h = traverse<ANY>(bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
+        const DHit h = traverse<ANY, LdsStack, COUNT>(bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, &tc);
         if (ANY) occluded[i] = h.prim >= 0 ? 1 : 0;
         else hits[i] = h;
+        if (COUNT && d.w > o.w) ++rays;
     }
     if (overflow) atomicOr(status, 1u);
+    if (COUNT)
+    {
+        /* measurement build only: per-lane sums -> three device counters */
+        atomicAdd(&work[0], (unsigned long long)tc.nodes);
+        atomicAdd(&work[1], (unsigned long long)tc.tris);
+        atomicAdd(&work[2], (unsigned long long)rays);
+    }
 }
 
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
@@ -63,7 +74,8 @@ int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, cons
     if (n <= 0) return PIMGPU_OK;
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
-    k_trace<false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status);
+    if (res->counting) k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
+    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }
@@ -74,7 +86,7 @@ int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const fl
     if (n <= 0) return PIMGPU_OK;
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
-    k_trace<true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status);
+    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }

@@ -153,9 +153,12 @@ struct LdsStack
  * ANY = false: closest hit (see contract above).  ANY = true: returns at the first accepted hit.
  * overflow: set to true when the stack was full and a subtree had to be dropped (the caller reports it).
  */
-template <bool ANY, class Stack>
+/* per-lane work counters of the measurement build (COUNT = true): nodes fetched (128 B each), triangles tested (48 B each) */
+struct TraverseCounts { uint32_t nodes, tris; };
+
+template <bool ANY, class Stack, bool COUNT = false>
 __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, float oz, float dx, float dy, float dz,
-    float tNear, float tFar, Stack& st, bool& overflow)
+    float tNear, float tFar, Stack& st, bool& overflow, TraverseCounts* counts = nullptr)
 {
     DHit h; h.prim = -1; h.t = tFar; h.u = 0.0f; h.v = 0.0f;
     if (!(tFar > tNear)) return h;
@@ -169,6 +172,7 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
     {
         if (cur >= 0)
         {
+            if (COUNT) counts->nodes++;
             const float4* q = nodes + (size_t)cur * 8;
             const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
             const float4 ch = q[6];
@@ -205,6 +209,7 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
             const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; ++k)
             {
+                if (COUNT) counts->tris++;
                 const float4* tp = tris + (size_t)(first + k) * 3;
                 const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
                 float t, u, v;
