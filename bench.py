@@ -49,7 +49,7 @@ def build_scene(kind):
         return scenes.cornell_box(), scenes.pt_test_camera()
     if kind == "synth1m":
         sc = scenes.synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, emissive_attempts=64)
-        return sc, scenes.camera((-40.0, 5.0, 40.0), (1.0, -0.2, -1.0))
+        return sc, scenes.synthetic_camera(100.0)
     raise ValueError(kind)
 
 
@@ -160,7 +160,7 @@ def main():
         # on one more frame of the same workload (outside the timed region)
         api.work_counters(True)
         step(args.steps)
-        nodes, tris, crays = api.work_counters(False)
+        nodes, tris, crays, worst = api.work_counters(False)
         crays = max(crays, 1)
         b_ray = 48.0 + 128.0 * nodes / crays + 48.0 * tris / crays
         achieved = rays * b_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
@@ -179,7 +179,7 @@ def main():
             "device_ms_per_step": total_ms / args.steps, "traversal_ms_per_step": trace_ms / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "bytes_per_ray": b_ray, "nodes_per_ray": nodes / crays, "tris_per_ray": tris / crays,
+                         "bytes_per_ray": b_ray, "nodes_per_ray": nodes / crays, "tris_per_ray": tris / crays, "max_nodes_one_ray": worst,
                          "rays_per_launch": rays / (args.steps * 2 * wl["bounces"]),
                          "avg_launch_ms": trace_ms / (args.steps * 2 * wl["bounces"])},
         }

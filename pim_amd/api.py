@@ -263,10 +263,10 @@ class Trace:
 
 
 def work_counters(enable):
-    """switch the counting build of the traversal kernel on/off; returns (nodes, triangles, rays) since the last call"""
-    out = (C.c_uint64 * 3)()
+    """switch the counting build of the traversal kernel on/off; returns (nodes, triangles, rays, worst ray's nodes) since the last call"""
+    out = (C.c_uint64 * 4)()
     check(load_library().pimgpu_work_counters(C.c_int(1 if enable else 0), out), "pimgpu_work_counters")
-    return int(out[0]), int(out[1]), int(out[2])
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
 
 def init(device=0):

@@ -162,8 +162,8 @@ int pimgpu_work_counters(int enable, uint64_t* out)
 {
     int rc = check_ready(); if (rc) return rc;
     PT_HIP(hipStreamSynchronize(g_lib.stream));
-    if (out) PT_HIP(hipMemcpy(out, g_lib.trace.work, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    PT_HIP(hipMemset(g_lib.trace.work, 0, 3 * sizeof(uint64_t)));
+    if (out) PT_HIP(hipMemcpy(out, g_lib.trace.work, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    PT_HIP(hipMemset(g_lib.trace.work, 0, 4 * sizeof(uint64_t)));
     g_lib.trace.counting = enable != 0;
     return PIMGPU_OK;
 }

@@ -531,6 +531,44 @@ int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why)
             }
         }
     }
+    /* boxes: every slot's box must contain the triangles below it (checked against the leaf triangles' own vertices) */
+    {
+        struct Item { int32_t node; float lo[3], hi[3]; };
+        std::vector<Item> st; 
+        Item root; root.node = 0; for (int a = 0; a < 3; ++a) { root.lo[a] = -3.0e38f; root.hi[a] = 3.0e38f; }
+        st.push_back(root);
+        while (!st.empty())
+        {
+            const Item it = st.back(); st.pop_back();
+            const float4* q = &nodes[(size_t)it.node * 8];
+            const float lx[4] = { q[0].x, q[0].y, q[0].z, q[0].w }, ly[4] = { q[1].x, q[1].y, q[1].z, q[1].w }, lz[4] = { q[2].x, q[2].y, q[2].z, q[2].w };
+            const float hx[4] = { q[3].x, q[3].y, q[3].z, q[3].w }, hy[4] = { q[4].x, q[4].y, q[4].z, q[4].w }, hz[4] = { q[5].x, q[5].y, q[5].z, q[5].w };
+            const float ch[4] = { q[6].x, q[6].y, q[6].z, q[6].w };
+            for (int k = 0; k < 4; ++k)
+            {
+                int32_t c; __builtin_memcpy(&c, &ch[k], 4);
+                if (c == PT_BVH_EMPTY) continue;
+                Item child; child.node = c;
+                child.lo[0] = lx[k]; child.lo[1] = ly[k]; child.lo[2] = lz[k]; child.hi[0] = hx[k]; child.hi[1] = hy[k]; child.hi[2] = hz[k];
+                for (int a = 0; a < 3; ++a)
+                {
+                    if (!(child.lo[a] >= it.lo[a] && child.hi[a] <= it.hi[a] && child.lo[a] <= child.hi[a]))
+                    { snprintf(buf, sizeof(buf), "node %d slot %d: box [%g,%g] on axis %d is not inside its parent's [%g,%g]", it.node, k, child.lo[a], child.hi[a], a, it.lo[a], it.hi[a]); *why = buf; return PIMGPU_E_STATE; }
+                }
+                if (c >= 0) { st.push_back(child); continue; }
+                const uint32_t code = (uint32_t)~c, first = code >> 3, cnt = (code & 7u) + 1u;
+                for (uint32_t t = first; t < first + cnt; ++t)
+                    for (int v = 0; v < 3; ++v)
+                    {
+                        const float4 p = tris[(size_t)t * 3 + v];
+                        const float pp[3] = { p.x, p.y, p.z };
+                        for (int a = 0; a < 3; ++a)
+                            if (!(pp[a] >= child.lo[a] && pp[a] <= child.hi[a]))
+                            { snprintf(buf, sizeof(buf), "node %d slot %d: triangle slot %u vertex %d (%g) outside the leaf box [%g,%g] on axis %d", it.node, k, t, v, pp[a], child.lo[a], child.hi[a], a); *why = buf; return PIMGPU_E_STATE; }
+                    }
+            }
+        }
+    }
     for (int32_t t = 0; t < n; ++t) if (!seenTri[(size_t)t]) { snprintf(buf, sizeof(buf), "triangle slot %d is not referenced by any leaf (%zu nodes visited)", t, visited); *why = buf; return PIMGPU_E_STATE; }
     return PIMGPU_OK;
 }

@@ -547,28 +547,41 @@ __global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restri
     }
 }
 
-/* CalcStdDev, render_system.c:1374-1394: serial fp32 accumulation in pixel order (one lane: the
- * summation order is part of the result) */
-__global__ void k_stddev(const float* __restrict__ color, int32_t len, float* __restrict__ out)
+/* CalcStdDev, render_system.c:1374-1394.  The reference accumulates mean and variance serially in fp32, in
+ * pixel order, and that order is part of the result.  Per-pixel terms are computed in parallel (k_stddev_terms);
+ * the two running sums are then formed by ONE lane in pixel order, the other 63 lanes of its wave only stage
+ * the terms through LDS (k_stddev_sum). */
+__global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ color, int32_t len, const float* __restrict__ meanIn,
+    float* __restrict__ terms)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float meanWeight = 1.0f / len;
-    const float varianceWeight = 1.0f / (len - 1);
-    float mean = 0.0f;
-    for (int32_t i = 0; i < len; ++i)
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
+    if (!meanIn) terms[i] = lum * (1.0f / len);                       /* mean += lum * meanWeight */
+    else
     {
-        const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
-        mean += lum * meanWeight;
+        const float err = lum - meanIn[0];
+        terms[i] = (1.0f / (len - 1)) * (err * err);                  /* variance += varianceWeight * (err * err) */
     }
-    float variance = 0.0f;
-    for (int32_t i = 0; i < len; ++i)
+}
+
+__global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
+{
+    constexpr int kTile = 2048;
+    __shared__ float tile[kTile];
+    float sum = 0.0f;
+    for (int32_t base = 0; base < len; base += kTile)
     {
-        const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
-        const float err = lum - mean;
-        variance += varianceWeight * (err * err);
+        for (int k = threadIdx.x; k < kTile; k += 64) tile[k] = (base + k < len) ? terms[base + k] : 0.0f;
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const int32_t m = min(kTile, len - base);
+            for (int32_t k = 0; k < m; ++k) sum += tile[k];
+        }
+        __syncthreads();
     }
-    out[0] = mean;
-    out[1] = pt_sqrt(variance);
+    if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(sum) : sum;
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -770,7 +783,14 @@ int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
     int rc = check_ready(); if (rc) return rc;
     if (!t) { set_error("trace_stddev: NULL trace"); return PIMGPU_E_INVALID; }
     float* outDev = (float*)g_lib.trace.status + 16;       /* spare words of the status block */
-    k_stddev<<<1, 64, 0, g_lib.stream>>>(t->color, t->width * t->height, outDev);
+    const int32_t len = t->width * t->height;
+    WorkBuffers& w = g_lib.work;
+    if ((rc = w.ensure_rays((len + 3) / 4 + 1))) return rc;  /* len floats of scratch in the packed-ray buffer */
+    float* terms = (float*)w.rayO;
+    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, nullptr, terms);
+    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev, 0);
+    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
+    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
     float h[2];
     PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));

@@ -49,11 +49,13 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     st.spill = spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x);
     bool overflow = false;
     TraverseCounts tc; tc.nodes = 0; tc.tris = 0;
-    uint32_t rays = 0;
+    uint32_t rays = 0, worst = 0;
     for (int32_t i = blockIdx.x * kTraceThreads + threadIdx.x; i < n; i += gridDim.x * kTraceThreads)
     {
         const float4 o = rayO[i], d = rayD[i];
+        const uint32_t nodesBefore = tc.nodes;
         const DHit h = traverse<ANY, LdsStack, COUNT>(bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, &tc);
+        if (COUNT) worst = max(worst, tc.nodes - nodesBefore);
         if (ANY) occluded[i] = h.prim >= 0 ? 1 : 0;
         else hits[i] = h;
         if (COUNT && d.w > o.w) ++rays;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
         atomicAdd(&work[0], (unsigned long long)tc.nodes);
         atomicAdd(&work[1], (unsigned long long)tc.tris);
         atomicAdd(&work[2], (unsigned long long)rays);
+        atomicMax(&work[3], (unsigned long long)worst);           /* most nodes any single ray fetched */
     }
 }
 

@@ -495,6 +495,22 @@ def _batch_flatten(mesh, T, Q, S):
     return P4, N4, U
 
 
+SYNTH_CAMERA_POS = (-0.4, 0.05, 0.4)      # x extent: where synthetic_camera() stands; kept clear of objects
+SYNTH_CAMERA_DIR = (1.0, -0.2, -1.0)
+
+
+def synthetic_camera(extent=100.0):
+    return camera(tuple(c * extent for c in SYNTH_CAMERA_POS), SYNTH_CAMERA_DIR)
+
+
+def _keep_clear(T, extent):
+    """mirror the objects that would swallow the camera position through the origin"""
+    cam = np.array(SYNTH_CAMERA_POS, F) * F(extent)
+    near = np.linalg.norm(T - cam[None, :], axis=1) < 0.04 * extent
+    T[near] = -T[near]
+    return T
+
+
 def synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, sphere_fraction=0.5, n_materials=64,
                     diffuse_only=False, emissive_attempts=64, meters_per_cell=None, sphere_vsteps=24):
     """BASELINE.json configs 3-5: random boxes (12 tris) and UV spheres (reference tessellation) in an
@@ -509,11 +525,20 @@ def synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, sphere_fract
     # room: six wall boxes + light panel, as in the Cornell recipe but scaled
     wallScale = _v3(extent, extent, 0.1 * extent / 10.0)
     wallMat = b.material((0.7, 0.7, 0.7, 1.0), (1.0 if diffuse_only else 0.9, 1.0, 0.0, 0.0))
+    wt = int(__import__("os").environ.get("PIM_WALL_TESS", "1"))      # experiment knob: tessellate the walls into wt x wt tiles
     for ft, fl in [(YM, YP), (YP, YM), (XM, XP), (XP, XM), (ZP, ZP), (ZM, ZM)]:
-        b.add(box, (K_FORWARDS[ft] * half).astype(F), quat_lookat(K_FORWARDS[fl], K_UPS[fl]), wallScale, wallMat)
+        if wt <= 1:
+            b.add(box, (K_FORWARDS[ft] * half).astype(F), quat_lookat(K_FORWARDS[fl], K_UPS[fl]), wallScale, wallMat)
+        else:
+            q = quat_lookat(K_FORWARDS[fl], K_UPS[fl])
+            c0, c1, c2 = quat_to_m33(q)
+            for iy in range(wt):
+                for ix in range(wt):
+                    off = c0 * F((ix + 0.5) / wt - 0.5) * F(extent) + c1 * F((iy + 0.5) / wt - 0.5) * F(extent)
+                    b.add(box, (K_FORWARDS[ft] * half + off).astype(F), q, _v3(extent / wt, extent / wt, wallScale[2]), wallMat)
     lightMat = b.material((1.0, 1.0, 1.0, 1.0), (0.9, 1.0, 0.0, 1.0))
     b.add(box, _v3(0, half - F(0.02 * extent), 0), quat_lookat(K_FORWARDS[YM], K_UPS[YM]), _v3(0.4 * extent, 0.4 * extent, 0.01 * extent), lightMat)
-    room_tris = 7 * 12
+    room_tris = (6 * wt * wt + 1) * 12
     mats = []
     for _ in range(n_materials):
         alb = rng.uniform(0.2, 0.9, 3)
@@ -525,12 +550,12 @@ def synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, sphere_fract
     n_box = (remaining - n_sph * sph_tris) // 12
     inner = extent * 0.5 * 0.9
     if n_sph:
-        T = rng.uniform(-inner, inner, (n_sph, 3)).astype(F)
+        T = _keep_clear(rng.uniform(-inner, inner, (n_sph, 3)).astype(F), extent)
         S = np.repeat(rng.uniform(0.004, 0.012, (n_sph, 1)) * extent, 3, 1).astype(F)
         P4, N4, U = _batch_flatten(sph, T, _random_quats(rng, n_sph), S)
         b.add_arrays(P4, N4, U, np.repeat(mats[rng.integers(0, n_materials, n_sph)], sph[0].shape[0]))
     if n_box:
-        T = rng.uniform(-inner, inner, (n_box, 3)).astype(F)
+        T = _keep_clear(rng.uniform(-inner, inner, (n_box, 3)).astype(F), extent)
         S = (rng.uniform(0.002, 0.012, (n_box, 3)) * extent).astype(F)
         P4, N4, U = _batch_flatten(box, T, _random_quats(rng, n_box), S)
         b.add_arrays(P4, N4, U, np.repeat(mats[rng.integers(0, n_materials, n_box)], 36))
