@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pim_amd import api, scenes  # noqa: E402
+from pim_amd import dist as pdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -115,7 +116,7 @@ def main():
     def step(i):
         # rank r renders samples r, r + world, ...; sampleWeight makes each rank's image its own running mean
         p = scenes.trace_params(i, seed=1, max_bounces=wl["bounces"])
-        p.sampleIndex = i * world + rank
+        p.sampleIndex = pdist.sample_indices(rank, world, i + 1)[i]
         trace.trace(scene, cam, dof, p)
         s = trace.stats()
         return s.extensionRays + s.shadowRays + s.otherRays, s.traceMs, s.totalMs
@@ -140,8 +141,7 @@ def main():
     if world > 1:
         # the path's one exchange step: sum of the per-GPU mean images on rank 0 (RCCL reduce over xGMI)
         trace.copy_dev(reduce_buf.data_ptr())
-        dist.reduce(reduce_buf, dst=0, op=dist.ReduceOp.SUM)
-        reduce_buf.mul_(1.0 / world)
+        pdist.reduce_mean_image(reduce_buf, world, dist, dst=0)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

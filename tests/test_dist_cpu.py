@@ -1,0 +1,75 @@
+"""CPU, world_size 2, gloo: the N > 1 path of bench.py -- sample sharding by index plus ONE reduce of the
+per-rank mean images -- gives the image a single process renders with all the samples (up to fp32 reassociation
+of the final mean), using the CPU oracle as the renderer on each rank; and the lightmap texel tiling is a
+partition."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pim_amd import dist as pdist  # noqa: E402
+
+W, H, STEPS = 48, 27, 3
+
+
+def _render(indices):
+    from pim_amd import scenes
+    from tests.util import OracleScene
+    sc = scenes.cornell_box(emissive_attempts=64)
+    o = OracleScene(sc.desc, accel=1, threads=2)
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dof = scenes.default_dof()
+    dof.autoFocus = 0
+    for k, s in enumerate(indices):
+        p = scenes.trace_params(k, seed=3, max_bounces=3, update_dists=0)
+        p.sampleIndex = s
+        o.trace_image(img, W, H, scenes.pt_test_camera(), dof, p)
+    return img[0]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = _render(pdist.sample_indices(rank, world, STEPS))
+    t = torch.from_numpy(mine.copy())
+    pdist.reduce_mean_image(t, world, dist, dst=0)
+    if rank == 0:
+        np.save(out, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_sharding_and_reduce_world2(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    # single process, same 6 samples: mean of the two shards' means == overall mean (equal counts)
+    a = _render(pdist.sample_indices(0, 2, STEPS))
+    b = _render(pdist.sample_indices(1, 2, STEPS))
+    assert np.array_equal(got, (a + b) * np.float32(0.5))
+    assert sorted(pdist.sample_indices(0, 2, STEPS) + pdist.sample_indices(1, 2, STEPS)) == list(range(2 * STEPS))
+    assert got.mean() > 0.01
+
+
+def test_texel_tiles_partition():
+    for total in (0, 1, 4095, 4096, 4097, 64 * 64 * 37 + 5):
+        for world in (1, 2, 3, 8):
+            seen = 0
+            prev_end = 0
+            for r in range(world):
+                b, e = pdist.texel_range(r, world, total)
+                assert b == prev_end or b == e == total
+                assert b % (64 * 64) == 0 or b == total
+                seen += e - b; prev_end = e
+            assert seen == total

@@ -1,0 +1,76 @@
+"""-m gpu: the plain-C host layer (pim_amd/host/pim_host.c: Pim's own entry-point names over the C-ABI)
+gives the same bits as the oracle: Pt_Trace's host images after several frames, Pt_Intersect, Pt_TraceRay."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pim_amd import api, scenes
+from tests.util import OracleScene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Int2(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
+
+
+class PtTrace(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("albedo", C.c_void_p), ("normal", C.c_void_p), ("denoised", C.c_void_p),
+                ("imageSize", Int2), ("sampleWeight", C.c_float), ("gpu", C.c_void_p), ("sampleIndex", C.c_uint32),
+                ("seed", C.c_uint32), ("maxBounces", C.c_int32), ("frameDt", C.c_float)]
+
+
+class PtRayHit(C.Structure):
+    _fields_ = [("wuvt", Float4), ("normal", Float4), ("type", C.c_int32), ("iVert", C.c_int32), ("flags", C.c_uint32)]
+
+
+class PtResult(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("albedo", C.c_float * 3), ("normal", C.c_float * 3)]
+
+
+def test_pim_named_entry_points_match_oracle():
+    host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
+    host.PtSys_Init.restype = C.c_bool
+    host.PtScene_New.restype = C.c_void_p
+    host.Pt_Intersect.restype = PtRayHit
+    host.Pt_Intersect.argtypes = [C.c_void_p, Float4, Float4, C.c_float, C.c_float]
+    host.Pt_TraceRay.restype = PtResult
+    host.Pt_TraceRay.argtypes = [C.c_void_p, Float4, Float4, C.c_uint32, C.c_uint32, C.c_int32]
+    assert host.PtSys_Init()
+    sc = scenes.cornell_box()
+    scene = C.c_void_p(host.PtScene_New(C.byref(sc.desc)))
+    assert scene
+    o = OracleScene(sc.desc, accel=1)
+    W, H = 80, 45
+    trace = PtTrace()
+    host.PtTrace_New(C.byref(trace), Int2(W, H))
+    trace.seed, trace.maxBounces = 17, 4
+    dof, dof_o = api.PimDofInfo(), scenes.default_dof()
+    host.DofInfo_New(C.byref(dof))
+    assert bytes(dof) == bytes(dof_o)
+    cam = scenes.pt_test_camera()
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    for s in range(3):
+        trace.sampleWeight = 1.0 / (s + 1)
+        host.Pt_Trace(C.byref(trace), C.byref(dof), scene, C.byref(cam))
+        o.trace_image(img, W, H, cam, dof_o, scenes.trace_params(s, seed=17, max_bounces=4))
+    color = np.ctypeslib.as_array(C.cast(trace.color, C.POINTER(C.c_float)), shape=(W * H, 3))
+    assert (color.view(np.uint32) == img[0].view(np.uint32)).all()
+    assert trace.sampleIndex == 3
+
+    ro = Float4(0.5, -1.0, 0.25, 0.0); rd = Float4(0.0, 0.6, 0.8, 0.0)
+    h = host.Pt_Intersect(scene, ro, rd, 0.0, api.RCP_EPSILON)
+    ho = o.intersect(np.array([[0.5, -1.0, 0.25, 0.0]], np.float32), np.array([[0.0, 0.6, 0.8, 0.0]], np.float32))[0]
+    assert h.type == ho["type"] and h.iVert == ho["iVert"] and np.float32(h.wuvt.w) == ho["wuvt"][3]
+    r = host.Pt_TraceRay(scene, ro, rd, 2, 5, 4)
+    r_o = o.trace_rays(np.array([[0.5, -1.0, 0.25, 0.0]], np.float32), np.array([[0.0, 0.6, 0.8, 0.0]], np.float32), 2, 5, 4)[0]
+    assert tuple(np.float32(v) for v in r.color) == tuple(r_o["color"])
+    host.PtTrace_Del(C.byref(trace))
+    host.PtScene_Del(scene)
