@@ -311,7 +311,7 @@ def foggy_media(mfp=8.0):
 def default_dof():
     """DofInfo_New, rendering/path_tracer.c:1141-1153"""
     d = api.PimDofInfo()
-    d.aperture = 5.0 * 1e-3
+    d.aperture = float(F(5.0) * F(1e-3))      # 5.0f * kMilli in fp32
     d.focalLength = 6.0
     d.bladeCount = 5
     d.bladeRot = float(kPi / F(10.0))
