@@ -74,6 +74,7 @@ static void scene_free(PimScene* s)
     for (void* p : s->texels) hipFree(p);
     for (int f = 0; f < 6; ++f) hipFree(s->sky[f]);
     hipFree(s->lut);
+    hipFree(s->sceneDev);
     hipFree(s->cellLength); hipFree(s->pdf); hipFree(s->cdf); hipFree(s->live); hipFree(s->cellSum); hipFree(s->cellIntegral);
     s->bvh.release();
     delete s;
@@ -92,6 +93,14 @@ static int check_status_word(const char* what)
     return PIMGPU_OK;
 }
 
+static int scene_sync_device_copy(PimScene* s)
+{
+    if (!s->sceneDev && hipMalloc(&s->sceneDev, sizeof(DScene)) != hipSuccess) { set_error("out of device memory"); return PIMGPU_E_NOMEM; }
+    PT_HIP(hipMemcpyAsync(s->sceneDev, &s->d, sizeof(DScene), hipMemcpyHostToDevice, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
 static int scene_build_bvh(PimScene* s)
 {
     hipEvent_t e0, e1;
@@ -104,6 +113,7 @@ static int scene_build_bvh(PimScene* s)
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (rc) { if (rc == PIMGPU_E_NOMEM) set_error("out of device memory building the BVH"); return rc; }
     s->d.bvh = s->bvh.view();
+    if ((rc = scene_sync_device_copy(s))) return rc;
     if (getenv("PIMGPU_VALIDATE_BVH"))
     {
         std::string why;
@@ -303,6 +313,7 @@ int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     s->setupMs = msEmit + msGrid;
+    if ((rc = scene_sync_device_copy(s))) return fail(rc);
     *out = s;
     return PIMGPU_OK;
 }

@@ -46,7 +46,7 @@ void WorkBuffers::release()
     hipFree(ps.rng); hipFree(ps.ro); hipFree(ps.rd); hipFree(ps.atten); hipFree(ps.lum); hipFree(ps.albedo); hipFree(ps.normal);
     hipFree(ps.nee0); hipFree(ps.nee1);
     for (int i = 0; i < 2; ++i) { hipFree(extO[i]); hipFree(extD[i]); hipFree(queue[i]); }
-    hipFree(neeO); hipFree(neeD); hipFree(extHit); hipFree(neeHit); hipFree(counters); hipFree(stats); hipFree(results);
+    hipFree(neeO); hipFree(neeD); hipFree(extHit); hipFree(neeHit); hipFree(counters); hipFree(stats); hipFree(results); hipFree(slowA); hipFree(slowB);
     *this = WorkBuffers();
 }
 
@@ -79,7 +79,7 @@ int WorkBuffers::ensure_paths(int64_t n)
     A(&ps.lum, sizeof(float4)); A(&ps.albedo, sizeof(float4)); A(&ps.normal, sizeof(float4));
     A(&ps.nee0, sizeof(float4)); A(&ps.nee1, sizeof(float4));
     for (int i = 0; i < 2; ++i) { A(&extO[i], sizeof(float4)); A(&extD[i], sizeof(float4)); A(&queue[i], sizeof(int32_t)); }
-    A(&neeO, sizeof(float4)); A(&neeD, sizeof(float4)); A(&extHit, sizeof(DHit)); A(&neeHit, sizeof(DHit)); A(&results, sizeof(PimResult));
+    A(&slowA, sizeof(int32_t)); A(&slowB, sizeof(int32_t)); A(&neeO, sizeof(float4)); A(&neeD, sizeof(float4)); A(&extHit, sizeof(DHit)); A(&neeHit, sizeof(DHit)); A(&results, sizeof(PimResult));
     if (!ok) { set_error("out of device memory for %lld paths", (long long)n); return PIMGPU_E_NOMEM; }
     pathCap = n;
     return PIMGPU_OK;
@@ -118,6 +118,7 @@ struct StageArgs
     PimResult* results;
     unsigned long long* stats;
     int32_t bounce, bounceLimit;
+    int32_t* slowA; int32_t* slowB; /* queue positions the FAST builds deferred (lengths: counters[2], counters[3]) */
 };
 
 __device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
@@ -147,6 +148,22 @@ __device__ __forceinline__ void wave_add(unsigned long long* dst, uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+/* wave-aggregated append: the lanes with `take` get consecutive positions of a device-side list (one atomic per wave) */
+__device__ __forceinline__ int32_t wave_append(int32_t* counter, bool take)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint64_t m = __ballot(take);
+    int32_t q0 = 0;
+    if (m)
+    {
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) q0 = atomicAdd(counter, (int32_t)__popcll(m));
+        q0 = __shfl(q0, leader, 64);
+    }
+    return q0 + (int32_t)__popcll(m & ltMask);
 }
 
 /* a fresh path in slot `slot`: Pt_TraceRay's locals (pt.c:2310-2317) + roulette of bounce 0 + extension ray 0 */
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, 
     if (i >= c.width * c.height) return;
     const int32_t cx = i % c.width, cy = i / c.width;
     const float rcpX = 1.0f / (float)c.width, rcpY = 1.0f / (float)c.height;
-    Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+    Ctx ctx = ctx_make();
     ctx.rng = pcg4((uint32_t)cx, (uint32_t)cy, c.sampleIndex, c.seed ^ PT_TAG_PIXEL);
     const v2 baseUv = f2_v((cx + 0.5f) * rcpX, (cy + 0.5f) * rcpY);
     const v2 aa = SampleGaussPixelFilter(Sample2D(ctx), 1.0f);
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, f
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+    Ctx ctx = ctx_make();
     ctx.rng = pcg4((uint32_t)i, sampleIndex, seed, PT_TAG_RAY);
     v4 o, d;
     if (ro) { o = ld4(ro, i); d = ld4(rd, i); }
@@ -237,21 +254,27 @@ __global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, f
 /* ---------------------------------------------------------------------------------------------- */
 /* shade_a: everything of a bounce between the extension hit and the direct-light ray              */
 
+template <bool SLOW>
 __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a)
 {
-    const int32_t count = a.counters[a.inSel];
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    const int32_t count = SLOW ? a.counters[2] : a.counters[a.inSel];
+    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0)
     {
         a.counters[a.inSel ^ 1] = 0;                         /* output queue of shade_b starts empty */
+        a.counters[3] = 0;                                   /* and so does shade_b's slow list */
         atomicAdd(&a.stats[0], (unsigned long long)count);   /* extension rays of this bounce */
     }
     uint32_t shadow = 0, other = 0; bool overflow = false;
     for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t pos = base + threadIdx.x;
-        if (pos >= count) continue;
+        const int32_t idx = base + threadIdx.x;
+        bool deferred = false;
+        int32_t pos = 0;
+        if (idx < count)
+        {
+        pos = SLOW ? a.slowA[idx] : idx;
         const int32_t slot = a.queueIn[pos];
-        Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+        Ctx ctx = ctx_make();
         { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
         const v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
         v4 attenuation = ld4(a.ps.atten, slot);
@@ -276,8 +299,12 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
         }
         else
         {
-            const Scatter ms = ScatterRay(ctx, s, ro, rd, hit.wuvt.w);                /* pt.c:2346-2367 */
-            if (ms.pdf > PT_EPS)
+            const Scatter ms = ScatterRay<SLOW>(ctx, s, ro, rd, hit.wuvt.w);          /* pt.c:2346-2367 */
+            if (!SLOW && ctx.defer)
+            {
+                /* the medium got in the way: nothing has been written yet, the SLOW build redoes this stage */
+            }
+            else if (ms.pdf > PT_EPS)
             {
                 luminance = f4_add(luminance, f4_mul(attenuation, ms.luminance));
                 attenuation = f4_mul(attenuation, f4_divs(ms.attenuation, ms.pdf));
@@ -336,7 +363,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
                         }
                         else
                         {
-                            const Scatter sample = Scatter_Principled(ctx, s, surf, rd);
+                            const Scatter sample = Scatter_Principled<SLOW>(ctx, s, surf, rd);   /* never refractive here */
                             const float brdfPdf = sample.pdf * pSmooth;
                             if (brdfPdf > PT_EPS)
                             {
@@ -351,6 +378,14 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
                 }
             }
         }
+        deferred = !SLOW && ctx.defer;
+        if (deferred)
+        {
+            /* park the lane's NEE slot (no ray) and leave the state as it was */
+            a.neeO[pos] = nO; a.neeD[pos] = nD;
+        }
+        else
+        {
         if (finished)
         {
             path_finish(a, slot, ctx, luminance, resultWeight, ld4(a.ps.albedo, slot), ld4(a.ps.normal, slot));
@@ -365,6 +400,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
         a.ps.nee0[slot] = nee0; a.ps.nee1[slot] = nee1;
         a.neeO[pos] = nO; a.neeD[pos] = nD;
         other += ctx.otherRays; overflow |= ctx.overflow;
+        }
+        }
+        if (!SLOW)
+        {
+            const int32_t q = wave_append(&a.counters[2], deferred);
+            if (deferred) a.slowA[q] = pos;
+        }
     }
     wave_add(&a.stats[1], shadow);
     wave_add(&a.stats[2], other);
@@ -374,27 +416,28 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
 /* ---------------------------------------------------------------------------------------------- */
 /* shade_b: from the direct-light hit to the next extension ray                                    */
 
+template <bool SLOW>
 __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a)
 {
-    const int32_t count = a.counters[a.inSel];
+    const int32_t count = SLOW ? a.counters[3] : a.counters[a.inSel];
     int32_t* countOut = &a.counters[a.inSel ^ 1];
+    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
     uint32_t other = 0; bool overflow = false;
-    const int lane = threadIdx.x & 63;
-    const uint64_t ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t pos = base + threadIdx.x;
-        bool alive = false;
-        int32_t slot = 0;
+        const int32_t idx = base + threadIdx.x;
+        bool alive = false, deferred = false;
+        int32_t slot = 0, pos = 0;
         v4 ro = f4_s(0.0f), rd = f4_s(0.0f);
-        if (pos < count)
+        if (idx < count)
         {
+            pos = SLOW ? a.slowB[idx] : idx;
             slot = a.queueIn[pos];
             const float4 nee0 = a.ps.nee0[slot];
             const int32_t mode = __float_as_int(nee0.x);
             if (mode != PT_NEE_DEAD)
             {
-                Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+                Ctx ctx = ctx_make();
                 { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
                 ro = ld4(a.ps.ro, slot); rd = ld4(a.ps.rd, slot);
                 v4 attenuation = ld4(a.ps.atten, slot);
@@ -420,7 +463,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
                         {
                             const int32_t iVert = __float_as_int(nee0.y);
                             const float selectPdf = nee0.z;
-                            const LightSample sample = SampleLight_finish(ctx, s, surf.P, iVert, nrd, nee0.w, nh);
+                            const LightSample sample = SampleLight_finish<SLOW>(ctx, s, surf.P, iVert, nrd, nee0.w, nh);
                             v4 L = sample.luminance;
                             const float lightPdf = sample.pdf * selectPdf * pRough;
                             if ((lightPdf > PT_EPS) && (f4_hmax3(L) > PT_EPS))
@@ -457,7 +500,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
                                 if (f4_hmax3(L) > PT_EPS)
                                 {
                                     L = f4_muls(L, PowerHeuristic(brdfPdf, lightPdf) / brdfPdf);
-                                    L = f4_mul(L, CalcTransmittance(ctx, s, surf.P, nrd, nh.wuvt.w));
+                                    L = f4_mul(L, CalcTransmittance<SLOW>(ctx, s, surf.P, nrd, nh.wuvt.w));
                                     Li = f4_add(Li, L);
                                 }
                             }
@@ -468,7 +511,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
                         luminance = f4_add(luminance, f4_mul(Li, attenuation));      /* pt.c:2385-2388 */
                         luminance.w = keep;
                     }
-                    const Scatter scatter = Scatter_Principled(ctx, s, surf, rd);      /* pt.c:2390 */
+                    const Scatter scatter = Scatter_Principled<SLOW>(ctx, s, surf, rd);  /* pt.c:2390 */
                     if (!(scatter.pdf > PT_EPS))
                     {
                         finished = true;                                              /* pt.c:2391-2394 */
@@ -491,7 +534,12 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
                     if (a.bounce + 1 >= a.bounceLimit) finished = true;
                     else if (!roulette(ctx, attenuation)) finished = true;
                 }
-                if (finished)
+                deferred = !SLOW && ctx.defer;
+                if (deferred)
+                {
+                    /* refraction or a collision on the light ray: nothing written, the SLOW build redoes this stage */
+                }
+                else if (finished)
                 {
                     path_finish(a, slot, ctx, luminance, resultWeight, albedoAcc, normalAcc);
                 }
@@ -505,24 +553,23 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
                     a.ps.lum[slot] = make_float4(luminance.x, luminance.y, luminance.z, __uint_as_float(prevFlags));
                     st4(a.ps.albedo, slot, albedoAcc); st4(a.ps.normal, slot, normalAcc);
                 }
-                other += ctx.otherRays; overflow |= ctx.overflow;
+                if (!deferred) { other += ctx.otherRays; overflow |= ctx.overflow; }
             }
         }
         /* russian-roulette compaction: survivors of this wave take consecutive queue positions */
-        const uint64_t m = __ballot(alive);
-        if (m)
         {
-            const int leader = __ffsll((long long)m) - 1;
-            int32_t q0 = 0;
-            if (lane == leader) q0 = atomicAdd(countOut, (int32_t)__popcll(m));
-            q0 = __shfl(q0, leader, 64);
+            const int32_t q = wave_append(countOut, alive);
             if (alive)
             {
-                const int32_t q = q0 + (int32_t)__popcll(m & ltMask);
                 a.queueOut[q] = slot;
                 a.extOOut[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
                 a.extDOut[q] = make_float4(rd.x, rd.y, rd.z, PT_RCP_EPS);
             }
+        }
+        if (!SLOW)
+        {
+            const int32_t q = wave_append(&a.counters[3], deferred);
+            if (deferred) a.slowB[q] = pos;
         }
     }
     wave_add(&a.stats[2], other);
@@ -592,10 +639,11 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
     WorkBuffers& w = g_lib.work;
     hipStream_t st = g_lib.stream;
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
-    const int32_t init[2] = { n, 0 };
+    const int32_t init[4] = { n, 0, 0, 0 };
     PT_HIP(hipMemcpyAsync(w.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(w.stats, 0, 64, st));
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * 8, ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
+    const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     float traceMs = 0.0f;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -608,15 +656,17 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
         a.ps = w.ps; a.queueIn = w.queue[in]; a.queueOut = w.queue[out]; a.counters = w.counters; a.inSel = in;
         a.extD = w.extD[in]; a.extHit = w.extHit; a.neeHit = w.neeHit; a.neeO = w.neeO; a.neeD = w.neeD;
         a.extOOut = w.extO[out]; a.extDOut = w.extD[out]; a.results = w.results; a.stats = w.stats;
-        a.bounce = b; a.bounceLimit = bounceLimit;
+        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA; a.slowB = w.slowB;
         if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
         if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[in], w.extD[in], w.extHit, n, w.counters + in, st))) break;
         if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
-        k_shade_a<<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        k_shade_a<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        k_shade_a<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
         if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.neeO, w.neeD, w.neeHit, n, w.counters + in, st))) break;
         if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
-        k_shade_b<<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
+        k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
         /* roulette-only termination (maxBounces <= 0): look at the queue length now and then */
         if (bounceLimit == 666 && b >= 7 && (b % 4) == 3)

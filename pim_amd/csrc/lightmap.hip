@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_bake_begin(BakeArgs b, PathState ps)
 
 __device__ __forceinline__ void path_start_bake(const PathState& ps, float4* extO, float4* extD, int32_t* queue, int32_t slot, v4 ro, v4 rd)
 {
-    Ctx ctx; ctx.shadowRays = ctx.otherRays = 0; ctx.overflow = false;
+    Ctx ctx = ctx_make();
     { const uint4 r = ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
     /* Pt_TraceRay's first roulette draw, pt.c:2321-2331 (attenuation = 1: always survives) */
     v4 attenuation = f4_s(1.0f);

@@ -10,6 +10,7 @@
 struct PimScene
 {
     pt::DScene d = {};
+    pt::DScene* sceneDev = nullptr;      /* copy of d in HBM (kernels take d by value; out-of-line device functions take this) */
     /* owned device memory */
     pt::v4* positions = nullptr; pt::v4* normals = nullptr; pt::v2* uvs = nullptr; int32_t* matIds = nullptr;
     int32_t* vertToEmit = nullptr; int32_t* emitToVert = nullptr;
@@ -61,7 +62,8 @@ struct WorkBuffers
     float4* neeO = nullptr; float4* neeD = nullptr;
     DHit* extHit = nullptr; DHit* neeHit = nullptr;
     int32_t* queue[2] = { nullptr, nullptr };
-    int32_t* counters = nullptr;        /* [0],[1]: queue lengths; device side */
+    int32_t* slowA = nullptr; int32_t* slowB = nullptr;     /* queue positions deferred to the SLOW builds of the stages */
+    int32_t* counters = nullptr;        /* [0],[1]: queue lengths; [2],[3]: slow-list lengths; device side */
     unsigned long long* stats = nullptr;/* ext, shadow, other rays */
     PimResult* results = nullptr;       /* per path slot */
     int ensure_rays(int64_t n);

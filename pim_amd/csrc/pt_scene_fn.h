@@ -120,13 +120,22 @@ __device__ __forceinline__ RayHit make_rayhit(const DScene& s, v4 rd, DHit h)
 }
 __device__ __forceinline__ int32_t hit_type(const DScene& s, v4 rd, DHit h) { return make_rayhit(s, rd, h).type; }
 
-/* per-path context: the RNG stream (PtContext, pt.c:168-176) + ray statistics */
-struct Ctx { u4 rng; uint32_t shadowRays, otherRays; bool overflow; };
+/* per-path context: the RNG stream (PtContext, pt.c:168-176) + ray statistics.
+ *
+ * FAST / SLOW builds.  A few rarely taken parts of a stage need many registers and a traversal stack: the
+ * medium's collision loop (with its in-scatter light ray), the transmittance loop, refraction (thickness ray).
+ * A kernel's register allocation is the maximum over everything it can reach, so keeping them in the same
+ * kernel would halve the occupancy of the common case.  Every stage is therefore built twice from one
+ * template: the FAST build (SLOW = false) only DETECTS the rare case -- before any side effect -- sets
+ * ctx.defer and the kernel drops the path's stage unfinished into a small "slow" list; the SLOW build runs
+ * the complete code on that list from the same saved state, redrawing the same random numbers. */
+struct Ctx { u4 rng; uint32_t shadowRays, otherRays; bool overflow; bool defer; };
 __device__ __forceinline__ float Sample1D(Ctx& c) { return rng_f32(&c.rng); }      /* pt.c:377 */
 __device__ __forceinline__ v2 Sample2D(Ctx& c) { return rng_f2(&c.rng); }          /* pt.c:382 */
+__device__ __forceinline__ Ctx ctx_make() { Ctx c; c.rng.x = c.rng.y = c.rng.z = c.rng.w = 0; c.shadowRays = c.otherRays = 0; c.overflow = false; c.defer = false; return c; }
 
-/* a closest-hit query traced inline by the calling lane (rare rays: media NEE, refraction thickness) */
-__device__ __noinline__ RayHit intersect_inline(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float tNear, float tFar)
+/* a closest-hit query traced inline by the calling lane (rare rays: media NEE, refraction thickness; SLOW builds only) */
+__device__ __forceinline__ RayHit intersect_inline(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float tNear, float tFar)
 {
     TrivialStack st;
     const DHit h = traverse<false>(s.bvh, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, tNear, tFar, st, ctx.overflow);
@@ -307,7 +316,7 @@ __device__ __forceinline__ Scatter Scatter_Specular(Ctx& ctx, const DScene& s, c
     return r;
 }
 
-__device__ __noinline__ Scatter Scatter_Refractive(Ctx& ctx, const DScene& s, const SurfHit& surf, v4 I)   /* pt.c:1576-1638 */
+__device__ __forceinline__ Scatter Scatter_Refractive(Ctx& ctx, const DScene& s, const SurfHit& surf, v4 I)   /* pt.c:1576-1638 */
 {
     const float etaI = 1.000277f;
     const float etaT = f1_max(1.0f, surf.ior);
@@ -368,9 +377,19 @@ __device__ __forceinline__ v4 Eval_Principled(const DScene& s, const SurfHit& su
     return evalA;
 }
 
+template <bool SLOW>
 __device__ __forceinline__ Scatter Scatter_Principled(Ctx& ctx, const DScene& s, const SurfHit& surf, v4 I)   /* pt.c:1670-1707 */
 {
-    if (surf.flags & PIM_MATFLAG_REFRACTIVE) return Scatter_Refractive(ctx, s, surf, I);
+    if (surf.flags & PIM_MATFLAG_REFRACTIVE)
+    {
+        if constexpr (SLOW) return Scatter_Refractive(ctx, s, surf, I);
+        else
+        {
+            ctx.defer = true;
+            Scatter none; none.pos = none.dir = none.attenuation = none.luminance = f4_s(0.0f); none.pdf = 0.0f;
+            return none;
+        }
+    }
     Scatter scatter;
     const float amtSpec = f1_lerp(0.5f, 1.0f, surf.metallic);
     const float amtDiffuse = 1.0f - amtSpec;
@@ -467,7 +486,10 @@ __device__ __forceinline__ v4 SamplePhaseDir(Ctx& ctx, const Media& media, v4 rd
     return L;
 }
 
-__device__ __forceinline__ v4 CalcTransmittance(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float rayLen)   /* pt.c:2223-2249 */
+/* CalcTransmittance, pt.c:2223-2249.  The first free-path sample ends the loop for all but a few rays in a thin
+ * medium (default mean free path 40 km); the FAST build defers the others. */
+template <bool SLOW>
+__device__ __forceinline__ v4 CalcTransmittance(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float rayLen)
 {
     const float rcpMaj = s.media.rcpMajorant;
     float t = 0.0f;
@@ -476,10 +498,14 @@ __device__ __forceinline__ v4 CalcTransmittance(Ctx& ctx, const DScene& s, v4 ro
     {
         const float dt = SampleFreePath(Sample1D(ctx), rcpMaj);
         if ((t + dt) >= rayLen) break;
-        const Media media = Media_Sample(s.media, f4_add(ro, f4_muls(rd, t)));
-        const v4 ratio = f4_inv(f4_muls(media.extinction, rcpMaj));
-        attenuation = f4_mul(attenuation, ratio);
-        t += dt;
+        if constexpr (!SLOW) { ctx.defer = true; break; }
+        else
+        {
+            const Media media = Media_Sample(s.media, f4_add(ro, f4_muls(rd, t)));
+            const v4 ratio = f4_inv(f4_muls(media.extinction, rcpMaj));
+            attenuation = f4_mul(attenuation, ratio);
+            t += dt;
+        }
     }
     return attenuation;
 }
@@ -499,6 +525,7 @@ __device__ __forceinline__ LightRay SampleLight_ray(Ctx& ctx, const DScene& s, v
     return lr;
 }
 /* SampleLight after its ray, pt.c:1813-1826 */
+template <bool SLOW>
 __device__ __forceinline__ LightSample SampleLight_finish(Ctx& ctx, const DScene& s, v4 ro, int32_t iVert, v4 rd, float distSq, const RayHit& hit)
 {
     LightSample sample;
@@ -511,7 +538,7 @@ __device__ __forceinline__ LightSample SampleLight_finish(Ctx& ctx, const DScene
         sample.luminance = GetEmission(s, rd, hit);
         if (f4_sum3(sample.luminance) > PT_EPS)
         {
-            const v4 Tr = CalcTransmittance(ctx, s, ro, rd, hit.wuvt.w);
+            const v4 Tr = CalcTransmittance<SLOW>(ctx, s, ro, rd, hit.wuvt.w);
             sample.luminance = f4_mul(sample.luminance, Tr);
         }
     }
@@ -519,7 +546,7 @@ __device__ __forceinline__ LightSample SampleLight_finish(Ctx& ctx, const DScene
 }
 
 /* EvaluateLight, pt.c:1921-1942 (media in-scatter; its light ray is traced inline) */
-__device__ __noinline__ bool EvaluateLight(Ctx& ctx, const DScene& s, v4 P, v4* lightOut, v4* dirOut)
+__device__ __forceinline__ bool EvaluateLight(Ctx& ctx, const DScene& s, v4 P, v4* lightOut, v4* dirOut)
 {
     int32_t iVert; float selectPdf;
     if (LightSelect(ctx, s, P, &iVert, &selectPdf))
@@ -527,7 +554,7 @@ __device__ __noinline__ bool EvaluateLight(Ctx& ctx, const DScene& s, v4 P, v4* 
         const LightRay lr = SampleLight_ray(ctx, s, P, iVert);
         ctx.otherRays++;
         const RayHit hit = intersect_inline(ctx, s, P, lr.rd, 0.0f, lr.distance + 0.01f * PT_MILLI);
-        const LightSample sample = SampleLight_finish(ctx, s, P, iVert, lr.rd, lr.distSq, hit);
+        const LightSample sample = SampleLight_finish<true>(ctx, s, P, iVert, lr.rd, lr.distSq, hit);
         if (sample.pdf > PT_EPS)
         {
             *lightOut = f4_divs(sample.luminance, sample.pdf * selectPdf);
@@ -538,7 +565,9 @@ __device__ __noinline__ bool EvaluateLight(Ctx& ctx, const DScene& s, v4 P, v4* 
     return false;
 }
 
-/* ScatterRay, pt.c:2251-2304 */
+/* ScatterRay, pt.c:2251-2304.  As with CalcTransmittance the first free-path sample usually reaches the surface;
+ * the FAST build defers the paths that collide with the medium. */
+template <bool SLOW>
 __device__ __forceinline__ Scatter ScatterRay(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float rayLen)
 {
     Scatter result;
@@ -552,27 +581,31 @@ __device__ __forceinline__ Scatter ScatterRay(Ctx& ctx, const DScene& s, v4 ro, 
         const float dt = SampleFreePath(Sample1D(ctx), rcpMaj);
         t += dt;
         if (t >= rayLen) break;
-        const v4 P = f4_add(ro, f4_muls(rd, t));
-        const Media media = Media_Sample(s.media, P);
-        const v4 ratio = f4_inv(f4_muls(media.extinction, rcpMaj));
-        result.attenuation = f4_mul(result.attenuation, ratio);
-        const float scatterProb = f4_hmax3(media.scattering) * rcpMaj;
-        if (Sample1D(ctx) < scatterProb)
+        if constexpr (!SLOW) { ctx.defer = true; break; }
+        else
         {
-            v4 lum, L;
-            if (EvaluateLight(ctx, s, P, &lum, &L))
+            const v4 P = f4_add(ro, f4_muls(rd, t));
+            const Media media = Media_Sample(s.media, P);
+            const v4 ratio = f4_inv(f4_muls(media.extinction, rcpMaj));
+            result.attenuation = f4_mul(result.attenuation, ratio);
+            const float scatterProb = f4_hmax3(media.scattering) * rcpMaj;
+            if (Sample1D(ctx) < scatterProb)
             {
-                const float ph = CalcPhase(media, f4_dot3(rd, L));
-                lum = f4_muls(lum, ph * dt);
-                lum = f4_mul(result.attenuation, lum);
-                result.luminance = lum;
+                v4 lum, L;
+                if (EvaluateLight(ctx, s, P, &lum, &L))
+                {
+                    const float ph = CalcPhase(media, f4_dot3(rd, L));
+                    lum = f4_muls(lum, ph * dt);
+                    lum = f4_mul(result.attenuation, lum);
+                    result.luminance = lum;
+                }
+                result.pos = P;
+                result.dir = SamplePhaseDir(ctx, media, rd);
+                result.pdf = result.dir.w;
+                const float ph = CalcPhase(media, f4_dot3(rd, result.dir));
+                result.attenuation = f4_muls(result.attenuation, ph);
+                break;
             }
-            result.pos = P;
-            result.dir = SamplePhaseDir(ctx, media, rd);
-            result.pdf = result.dir.w;
-            const float ph = CalcPhase(media, f4_dot3(rd, result.dir));
-            result.attenuation = f4_muls(result.attenuation, ph);
-            break;
         }
     }
     return result;

@@ -575,6 +575,23 @@ def random_rays(scene, n, seed=0, kind="inside"):
     return ro, rd
 
 
+def surface_rays(scene, n, seed=0, offset=1e-4):
+    """incoherent secondary rays (SURVEY 8d microbenchmark): origins uniformly on random triangles (+offset*N),
+    directions uniform in the hemisphere of the geometric normal, in shuffled order"""
+    rng = np.random.default_rng(seed)
+    tri = rng.integers(0, scene.tri_count, n)
+    P = scene.positions[:, :3].reshape(-1, 3, 3)[tri]
+    w = rng.dirichlet([1, 1, 1], n).astype(F)
+    p = (P * w[:, :, None]).sum(1)
+    nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where((d * nrm).sum(1, keepdims=True) < 0, -d, d)
+    ro = np.zeros((n, 4), F); rd = np.zeros((n, 4), F)
+    ro[:, :3] = p + nrm * offset; rd[:, :3] = d
+    return ro, rd
+
+
 def lightmap_pages_for(scene, lm_size, texels_per_meter, max_pages=None):
     """Synthetic bake inputs (the atlas packer is out of scope): every triangle gets
     its own chart rasterised at texels_per_meter into lm_size^2 pages in triangle order; covered texels get
