@@ -12,7 +12,7 @@ import numpy as np
 
 C = ctypes
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpimgpu.so")
+LIB_PATH = os.environ.get("PIMGPU_LIB", os.path.join(HERE, "libpimgpu.so"))     # override: A/B experiments only
 
 PIMGPU_OK = 0
 MATFLAG_EMISSIVE = 1 << 0

@@ -31,7 +31,10 @@
 
 namespace pt {
 
-static constexpr int kShadeThreads = 256;
+static constexpr int kShadeThreads = 512;
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4      /* waves per SIMD the FAST shade builds are compiled for (<= 128 VGPRs) */
+#endif
 
 /* nee0.x modes between shade_a and shade_b */
 #define PT_NEE_NONE   0     /* no direct-light ray this bounce */
@@ -166,6 +169,44 @@ __device__ __forceinline__ int32_t wave_append(int32_t* counter, bool take)
     return q0 + (int32_t)__popcll(m & ltMask);
 }
 
+/* block-aggregated append: ONE returning atomic per workgroup (a single device-scope counter sustains only ~90
+ * returning atomics per microsecond, MI355X_MICROARCH.md "dequeue": one per wave made the compaction, not the
+ * shading, the cost of shade_b).  Must be called by every thread of the block; sh is 2 + blockDim/64 ints of LDS. */
+__device__ __forceinline__ int32_t block_append(int32_t* counter, bool take, int32_t* sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint64_t m = __ballot(take);
+    if (lane == 0) sh[2 + wave] = (int32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int32_t total = 0;
+        for (int w = 0; w < nw; ++w) { const int32_t c = sh[2 + w]; sh[2 + w] = total; total += c; }
+        sh[0] = total ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    const int32_t q = sh[0] + sh[2 + wave] + (int32_t)__popcll(m & ltMask);
+    __syncthreads();
+    return q;
+}
+
+/* block-aggregated statistics add */
+__device__ __forceinline__ void block_add(unsigned long long* dst, uint32_t v, int32_t* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) sh[2 + wave] = (int32_t)v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        unsigned long long total = 0;
+        for (int w = 0; w < nw; ++w) total += (uint32_t)sh[2 + w];
+        if (total) atomicAdd(dst, total);
+    }
+    __syncthreads();
+}
+
 /* a fresh path in slot `slot`: Pt_TraceRay's locals (pt.c:2310-2317) + roulette of bounce 0 + extension ray 0 */
 __device__ __forceinline__ void path_start(const PathState& ps, float4* extO, float4* extD, int32_t* queue, int32_t slot, Ctx& ctx, v4 ro, v4 rd)
 {
@@ -255,7 +296,7 @@ __global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, f
 /* shade_a: everything of a bounce between the extension hit and the direct-light ray              */
 
 template <bool SLOW>
-__global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a)
+__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_a(DScene s, StageArgs a)
 {
     const int32_t count = SLOW ? a.counters[2] : a.counters[a.inSel];
     if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0)
@@ -408,8 +449,9 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
             if (deferred) a.slowA[q] = pos;
         }
     }
-    wave_add(&a.stats[1], shadow);
-    wave_add(&a.stats[2], other);
+    __shared__ int32_t sh[2 + kShadeThreads / 64];
+    block_add(&a.stats[1], shadow, sh);
+    block_add(&a.stats[2], other, sh);
     if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
 }
 
@@ -417,11 +459,12 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_a(DScene s, StageArgs a
 /* shade_b: from the direct-light hit to the next extension ray                                    */
 
 template <bool SLOW>
-__global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a)
+__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_b(DScene s, StageArgs a)
 {
     const int32_t count = SLOW ? a.counters[3] : a.counters[a.inSel];
     int32_t* countOut = &a.counters[a.inSel ^ 1];
     if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
+    __shared__ int32_t sh[2 + kShadeThreads / 64];
     uint32_t other = 0; bool overflow = false;
     for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
@@ -558,7 +601,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
         }
         /* russian-roulette compaction: survivors of this wave take consecutive queue positions */
         {
-            const int32_t q = wave_append(countOut, alive);
+            const int32_t q = block_append(countOut, alive, sh);
             if (alive)
             {
                 a.queueOut[q] = slot;
@@ -572,7 +615,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_b(DScene s, StageArgs a
             if (deferred) a.slowB[q] = pos;
         }
     }
-    wave_add(&a.stats[2], other);
+    block_add(&a.stats[2], other, sh);
     if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
 }
 
@@ -642,7 +685,7 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
     const int32_t init[4] = { n, 0, 0, 0 };
     PT_HIP(hipMemcpyAsync(w.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(w.stats, 0, 64, st));
-    const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * 8, ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
+    const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     float traceMs = 0.0f;
