@@ -28,6 +28,7 @@
 #include "pt_scene_fn.h"
 
 #include <cstring>
+#include <cstdlib>
 
 namespace pt {
 
@@ -690,7 +691,7 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
     hipEvent_t t0 = nullptr, t1 = nullptr;
     float traceMs = 0.0f;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    const bool timeTrace = traceMsOut != nullptr;
+    const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
     int rc = PIMGPU_OK;
     for (int32_t b = 0; b < bounceLimit; ++b)
     {

@@ -54,7 +54,9 @@ struct DGrid { v4 lo, hi; int32_t sx, sy, sz; float cellsPerMeter; };
  * p0.xyz + primID bits in w, p1.xyz, p2.xyz); empty slots have an inverted box and PT_BVH_EMPTY.
  */
 #define PT_BVH_EMPTY  ((int32_t)0x80000000)
+#ifndef PT_LEAF_MAX
 #define PT_LEAF_MAX   4
+#endif
 
 struct DBvh
 {
