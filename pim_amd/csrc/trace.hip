@@ -36,6 +36,20 @@ void TraceResources::release()
     spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
+/*
+ * The kernel is a per-lane state machine, not a per-ray function call: every trip of the wave's loop
+ * a lane tests ONE node (4 boxes), then ONE triangle, then pops -- whichever its state asks for -- so
+ * a wave never sits through a whole leaf (up to PT_LEAF_MAX triangles) for the sake of one lane, and
+ * lanes whose ray has finished are REFILLED from the wave's own contiguous slice of the ray array once
+ * PT_REFILL_IDLE of them are idle, instead of idling until the slowest ray of the wave is done.
+ * `cur` holds the state: >= 0 node index; < 0 leaf code ~((first << 3) | (count - 1)), stepped by
+ * code + 7 per triangle (first + 1, count - 1); PT_BVH_EMPTY = "pop next".
+ * Which lane traces which ray does not influence the ray's result (traverse.h contract).
+ */
+#ifndef PT_REFILL_IDLE
+#define PT_REFILL_IDLE 16
+#endif
+
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
@@ -47,27 +61,144 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     st.lds = sStack + threadIdx.x; st.ldsStride = kTraceThreads;
     st.spillStride = (int64_t)gridDim.x * kTraceThreads;
     st.spill = spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x);
+    st.init();
     bool overflow = false;
-    TraverseCounts tc; tc.nodes = 0; tc.tris = 0;
-    uint32_t rays = 0, worst = 0;
-    for (int32_t i = blockIdx.x * kTraceThreads + threadIdx.x; i < n; i += gridDim.x * kTraceThreads)
+    uint32_t cNodes = 0, cTris = 0, cRays = 0, cWorst = 0, rayNodes = 0;
+
+    /* this wave's slice of the rays: contiguous, a multiple of 64 long */
+    const int32_t wavesTotal = (int32_t)gridDim.x * (kTraceThreads / 64);
+    const int32_t wave = (int32_t)blockIdx.x * (kTraceThreads / 64) + (int32_t)(threadIdx.x >> 6);
+    const int64_t per = ((((int64_t)n + wavesTotal - 1) / wavesTotal) + 63) & ~(int64_t)63;
+    int32_t cursor = (int32_t)min((int64_t)n, per * wave);
+    const int32_t sliceEnd = (int32_t)min((int64_t)n, per * (wave + 1));
+
+    const float4* __restrict__ nodes = bvh.nodes;
+    const float4* __restrict__ tris = bvh.tris;
+
+    bool active = false;
+    int32_t ri = 0, cur = PT_BVH_EMPTY;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f, ix = 0.0f, iy = 0.0f, iz = 0.0f, tNear = 0.0f;
+    RayPre r = {};
+    DHit h = {};
+
+    for (;;)
     {
-        const float4 o = rayO[i], d = rayD[i];
-        const uint32_t nodesBefore = tc.nodes;
-        const DHit h = traverse<ANY, LdsStack, COUNT>(bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, &tc);
-        if (COUNT) worst = max(worst, tc.nodes - nodesBefore);
-        if (ANY) occluded[i] = h.prim >= 0 ? 1 : 0;
-        else hits[i] = h;
-        if (COUNT && d.w > o.w) ++rays;
+        /* refill idle lanes with the next rays of the slice */
+        {
+            const unsigned long long idle = __ballot(!active);
+            if (cursor < sliceEnd && idle != 0ull)
+            {
+                const int32_t rank = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const int32_t mine = cursor + rank;
+                if (!active && mine < sliceEnd)
+                {
+                    const float4 o = rayO[mine], d = rayD[mine];
+                    ri = mine;
+                    h.prim = -1; h.t = d.w; h.u = 0.0f; h.v = 0.0f;
+                    if (d.w > o.w)
+                    {
+                        r = ray_pre(o.x, o.y, o.z, d.x, d.y, d.z);
+                        ox = o.x; oy = o.y; oz = o.z; tNear = o.w;
+                        ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+                        cur = 0; active = true;
+                        if (COUNT) { ++cRays; rayNodes = 0; }
+                    }
+                    else
+                    {
+                        if (ANY) occluded[ri] = 0; else hits[ri] = h;
+                    }
+                }
+                cursor = min(sliceEnd, cursor + (int32_t)__popcll(idle));
+            }
+            if (__ballot(active) == 0ull)
+            {
+                if (cursor >= sliceEnd) break;
+                continue;
+            }
+        }
+        for (;;)
+        {
+            /* A: one node */
+            if (active && cur >= 0)
+            {
+                if (COUNT) { ++cNodes; ++rayNodes; }
+                const float4* q = nodes + (size_t)cur * 8;
+                const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+                const float4 ch = q[6];
+                float d[4]; int32_t c[4];
+                c[0] = __float_as_int(ch.x); c[1] = __float_as_int(ch.y); c[2] = __float_as_int(ch.z); c[3] = __float_as_int(ch.w);
+                const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+                const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const float ax = (lx[k] - ox) * ix, bx = (hx[k] - ox) * ix;
+                    const float ay = (ly[k] - oy) * iy, by = (hy[k] - oy) * iy;
+                    const float az = (lz[k] - oz) * iz, bz = (hz[k] - oz) * iz;
+                    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
+                    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
+                    t1 = fminf(t1, h.t);
+                    d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
+                }
+                PT_SWAP_IF(d[0], c[0], d[1], c[1]);
+                PT_SWAP_IF(d[2], c[2], d[3], c[3]);
+                PT_SWAP_IF(d[0], c[0], d[2], c[2]);
+                PT_SWAP_IF(d[1], c[1], d[3], c[3]);
+                PT_SWAP_IF(d[1], c[1], d[2], c[2]);
+                if (d[3] < __builtin_inff()) overflow |= !st.push(d[3], c[3]);
+                if (d[2] < __builtin_inff()) overflow |= !st.push(d[2], c[2]);
+                if (d[1] < __builtin_inff()) overflow |= !st.push(d[1], c[1]);
+                cur = (d[0] < __builtin_inff()) ? c[0] : PT_BVH_EMPTY;
+            }
+            /* B: one triangle of the current leaf */
+            bool finished = false;
+            if (active && cur < 0 && cur != PT_BVH_EMPTY)
+            {
+                if (COUNT) ++cTris;
+                const uint32_t code = (uint32_t)~cur;
+                const float4* tp = tris + (size_t)(code >> 3) * 3;
+                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                float t, u, v;
+                if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v))
+                {
+                    hit_consider(h, __float_as_int(p0.w), t, u, v);
+                    if (ANY) finished = true;
+                }
+                cur = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
+            }
+            /* C: pop, culling entries that start beyond the current closest hit */
+            if (active && (finished || cur == PT_BVH_EMPTY))
+            {
+                if (!finished)
+                {
+                    float t; int32_t c;
+                    finished = true;
+                    while (st.pop(&t, &c))
+                    {
+                        if (t <= h.t) { cur = c; finished = false; break; }
+                    }
+                }
+                if (finished)
+                {
+                    if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
+                    else hits[ri] = h;
+                    if (COUNT) cWorst = max(cWorst, rayNodes);
+                    st.init();
+                    active = false;
+                }
+            }
+            const int32_t idleCount = (int32_t)__popcll(__ballot(!active));
+            if (idleCount == 64 || (idleCount >= PT_REFILL_IDLE && cursor < sliceEnd)) break;
+        }
     }
     if (overflow) atomicOr(status, 1u);
     if (COUNT)
     {
-        /* measurement build only: per-lane sums -> three device counters */
-        atomicAdd(&work[0], (unsigned long long)tc.nodes);
-        atomicAdd(&work[1], (unsigned long long)tc.tris);
-        atomicAdd(&work[2], (unsigned long long)rays);
-        atomicMax(&work[3], (unsigned long long)worst);           /* most nodes any single ray fetched */
+        /* measurement build only: per-lane sums -> device counters */
+        atomicAdd(&work[0], (unsigned long long)cNodes);
+        atomicAdd(&work[1], (unsigned long long)cTris);
+        atomicAdd(&work[2], (unsigned long long)cRays);
+        atomicMax(&work[3], (unsigned long long)cWorst);           /* most nodes any single ray fetched */
     }
 }
 
