@@ -189,13 +189,17 @@ static OrcHit closest_brute(const OrcScene* s, v4 ro, v4 rd, float tNear, float 
     return h;
 }
 
-static inline bool box_test(const OrcNode* n, const float o[3], const float inv[3], float tNear, float tFar)
+/* The fp32 triangle test accepts the triangle perturbed by a few ulp of |p - o| (grazing hits, hits a hair
+ * behind the origin that round to a positive t), and the contract is "the test over ALL triangles"
+ * (closest_brute): a box may only cull what the test cannot accept, so every box is grown per ray by
+ * e = 2^-18 * (max|o| + max|scene coordinate|): lo planes are tested from o + e, hi planes from o - e. */
+static inline bool box_test(const OrcNode* n, const float op[3], const float om[3], const float inv[3], float tNear, float tFar)
 {
     float t0 = tNear, t1 = tFar;
     for (int a = 0; a < 3; ++a)
     {
-        float ta = (n->lo[a] - o[a]) * inv[a];
-        float tb = (n->hi[a] - o[a]) * inv[a];
+        float ta = (n->lo[a] - op[a]) * inv[a];
+        float tb = (n->hi[a] - om[a]) * inv[a];
         float lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
         hi *= 1.0000004f;                       /* conservative slab (Ize 2013) */
         if (!(lo != lo)) t0 = lo > t0 ? lo : t0;
@@ -208,14 +212,18 @@ static OrcHit closest_bvh(const OrcScene* s, v4 ro, v4 rd, float tNear, float tF
 {
     OrcRayPre r; ray_pre(&r, ro, rd);
     OrcHit h; h.prim = -1; h.t = tFar; h.u = h.v = 0.0f;
-    const float o[3] = { ro.x, ro.y, ro.z };
     const float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
+    float sceneMaxAbs = 0.0f;
+    for (int a = 0; a < 3; ++a) sceneMaxAbs = fmaxf(sceneMaxAbs, fmaxf(fabsf(s->nodes[0].lo[a]), fabsf(s->nodes[0].hi[a])));
+    const float e = 0x1p-18f * (fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)) + sceneMaxAbs);
+    const float op[3] = { ro.x + e, ro.y + e, ro.z + e };
+    const float om[3] = { ro.x - e, ro.y - e, ro.z - e };
     int32_t stack[128]; int sp = 0;
     stack[sp++] = 0;
     while (sp)
     {
         const OrcNode* n = &s->nodes[stack[--sp]];
-        if (!box_test(n, o, inv, tNear, h.t)) continue;
+        if (!box_test(n, op, om, inv, tNear, h.t)) continue;
         if (n->count)
         {
             for (int32_t k = 0; k < n->count; ++k)

@@ -375,7 +375,15 @@ __global__ __launch_bounds__(256) void k_emit_wide(int32_t n, const uint32_t* __
     q[4] = make_float4(slot[0].hi[1], slot[1].hi[1], slot[2].hi[1], slot[3].hi[1]);
     q[5] = make_float4(slot[0].hi[2], slot[1].hi[2], slot[2].hi[2], slot[3].hi[2]);
     q[6] = make_float4(__int_as_float(slot[0].child), __int_as_float(slot[1].child), __int_as_float(slot[2].child), __int_as_float(slot[3].child));
-    q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    /* node 0's spare quad carries the largest |coordinate| of the scene: the traversal pads every box by a
+     * per-ray epsilon proportional to (|origin| + this), see traverse.h */
+    float maxAbs = 0.0f;
+    if (i == 0)
+    {
+        const float4 rl = nodeLo[0], rh = nodeHi[0];
+        maxAbs = fmaxf(fmaxf(fmaxf(fabsf(rl.x), fabsf(rl.y)), fabsf(rl.z)), fmaxf(fmaxf(fabsf(rh.x), fabsf(rh.y)), fabsf(rh.z)));
+    }
+    q[7] = make_float4(maxAbs, 0.0f, 0.0f, 0.0f);
 }
 
 /* scenes of at most PT_LEAF_MAX triangles: one node, one leaf */
@@ -398,7 +406,8 @@ __global__ void k_emit_single(int32_t n, const float4* __restrict__ triLo, const
     wide[4] = make_float4(hi[1], -inf, -inf, -inf);
     wide[5] = make_float4(hi[2], -inf, -inf, -inf);
     wide[6] = make_float4(__int_as_float(leaf), __int_as_float(PT_BVH_EMPTY), __int_as_float(PT_BVH_EMPTY), __int_as_float(PT_BVH_EMPTY));
-    wide[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float maxAbs = n > 0 ? fmaxf(fmaxf(fmaxf(fabsf(lo[0]), fabsf(lo[1])), fabsf(lo[2])), fmaxf(fmaxf(fabsf(hi[0]), fabsf(hi[1])), fabsf(hi[2]))) : 0.0f;
+    wide[7] = make_float4(maxAbs, 0.0f, 0.0f, 0.0f);
 }
 
 __global__ __launch_bounds__(256) void k_emit_tris(const v4* __restrict__ positions, const uint32_t* __restrict__ vals,

@@ -55,7 +55,7 @@ struct DGrid { v4 lo, hi; int32_t sx, sy, sz; float cellsPerMeter; };
  */
 #define PT_BVH_EMPTY  ((int32_t)0x80000000)
 #ifndef PT_LEAF_MAX
-#define PT_LEAF_MAX   4
+#define PT_LEAF_MAX   2
 #endif
 
 struct DBvh

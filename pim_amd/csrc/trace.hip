@@ -9,32 +9,13 @@
  */
 #include "pt_host.h"
 #include "traverse.h"
+#include <cstdlib>
+#include <algorithm>
 
 namespace pt {
 
 static constexpr int kTraceThreads = 256;
 static constexpr int kTraceBlocksPerCU = 8;
-
-int TraceResources::ensure()
-{
-    if (spill) return PIMGPU_OK;
-    int dev = 0; hipDeviceProp_t prop;
-    PT_HIP(hipGetDevice(&dev));
-    PT_HIP(hipGetDeviceProperties(&prop, dev));
-    gridBlocks = prop.multiProcessorCount * kTraceBlocksPerCU;
-    const size_t lanes = (size_t)gridBlocks * kTraceThreads;
-    PT_HIP(hipMalloc(&spill, sizeof(uint2) * lanes * PT_STACK_SPILL));
-    PT_HIP(hipMalloc(&status, 256));
-    PT_HIP(hipMemset(status, 0, 256));
-    work = (unsigned long long*)(status + 32);       /* bytes 128..: nodes, tris, rays of the counting build */
-    return PIMGPU_OK;
-}
-
-void TraceResources::release()
-{
-    hipFree(spill); hipFree(status);
-    spill = nullptr; status = nullptr; gridBlocks = 0;
-}
 
 /*
  * The kernel is a per-lane state machine, not a per-ray function call: every trip of the wave's loop
@@ -77,7 +58,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
 
     bool active = false;
     int32_t ri = 0, cur = PT_BVH_EMPTY;
-    float ox = 0.0f, oy = 0.0f, oz = 0.0f, ix = 0.0f, iy = 0.0f, iz = 0.0f, tNear = 0.0f;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, tNear = 0.0f;
+    RayPad pad = {};
     RayPre r = {};
     DHit h = {};
 
@@ -98,7 +80,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                     if (d.w > o.w)
                     {
                         r = ray_pre(o.x, o.y, o.z, d.x, d.y, d.z);
-                        ox = o.x; oy = o.y; oz = o.z; tNear = o.w;
+                        pad = ray_pad(o.x, o.y, o.z, nodes[7].x);
+                        tNear = o.w;
                         ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
                         cur = 0; active = true;
                         if (COUNT) { ++cRays; rayNodes = 0; }
@@ -132,9 +115,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
-                    const float ax = (lx[k] - ox) * ix, bx = (hx[k] - ox) * ix;
-                    const float ay = (ly[k] - oy) * iy, by = (hy[k] - oy) * iy;
-                    const float az = (lz[k] - oz) * iz, bz = (hz[k] - oz) * iz;
+                    const float ax = (lx[k] - pad.xp) * ix, bx = (hx[k] - pad.xm) * ix;
+                    const float ay = (ly[k] - pad.yp) * iy, by = (hy[k] - pad.ym) * iy;
+                    const float az = (lz[k] - pad.zp) * iz, bz = (hz[k] - pad.zm) * iz;
                     float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
                     float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
                     t1 = fminf(t1, h.t);
@@ -200,6 +183,32 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
         atomicAdd(&work[2], (unsigned long long)cRays);
         atomicMax(&work[3], (unsigned long long)cWorst);           /* most nodes any single ray fetched */
     }
+}
+
+int TraceResources::ensure()
+{
+    if (spill) return PIMGPU_OK;
+    int dev = 0; hipDeviceProp_t prop;
+    PT_HIP(hipGetDevice(&dev));
+    PT_HIP(hipGetDeviceProperties(&prop, dev));
+    /* persistent grid = exactly the blocks that are resident at once (each wave owns a fixed slice of the rays) */
+    int perCU = kTraceBlocksPerCU;
+    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace<false, false>, kTraceThreads, 0));
+    perCU = std::max(1, std::min(perCU, kTraceBlocksPerCU));
+    if (const char* e = getenv("PIMGPU_TRACE_BLOCKS_PER_CU")) perCU = std::max(1, std::min(16, atoi(e)));      /* tuning knob */
+    gridBlocks = prop.multiProcessorCount * perCU;
+    const size_t lanes = (size_t)gridBlocks * kTraceThreads;
+    PT_HIP(hipMalloc(&spill, sizeof(uint2) * lanes * PT_STACK_SPILL));
+    PT_HIP(hipMalloc(&status, 256));
+    PT_HIP(hipMemset(status, 0, 256));
+    work = (unsigned long long*)(status + 32);       /* bytes 128..: nodes, tris, rays of the counting build */
+    return PIMGPU_OK;
+}
+
+void TraceResources::release()
+{
+    hipFree(spill); hipFree(status);
+    spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,

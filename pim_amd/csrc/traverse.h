@@ -9,6 +9,13 @@
  *     fallback, written without FMA contraction so the host evaluates the same bits;
  *   - u = weight of p1, v = weight of p2 (Embree's convention, RTC_GEOMETRY_TYPE_TRIANGLE).
  *
+ * Boxes and the fp32 triangle test: the test works on vertices translated by the ray origin, so what it
+ * accepts is the triangle perturbed by a few ulp of |p - o| (laterally and in t; grazing and just-behind-the-
+ * origin configurations give accepted "hits" whose exact-arithmetic t is slightly outside (tNear, tFar]).
+ * The contract defines the answer as the fp32 test over ALL triangles, so a box may only cull what the
+ * test cannot accept: every box is grown, per ray, by  e = 2^-18 * (max|o| + max|scene coordinate|)
+ * (>= 8x the test's error bound) by testing it against the origins o + e / o - e (ray_pad below).
+ *
  * Stack: entries are (entry distance, child).  The first PT_STACK_LDS entries of a lane live in LDS
  * (lane-interleaved, conflict free), deeper ones in a global spill area; TrivialStack keeps all of
  * them in per-lane scratch for the rare rays that shading code traces inline.
@@ -49,6 +56,17 @@ __device__ __forceinline__ RayPre ray_pre(float ox, float oy, float oz, float dx
     r.Sz = 1.0f / dmax;
     r.ox = ox; r.oy = oy; r.oz = oz;
     return r;
+}
+
+/* per-ray box padding (see header): lo planes are tested from o + e, hi planes from o - e */
+struct RayPad { float xp, yp, zp, xm, ym, zm; };
+__device__ __forceinline__ RayPad ray_pad(float ox, float oy, float oz, float sceneMaxAbs)
+{
+    const float e = 0x1p-18f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + sceneMaxAbs);
+    RayPad p;
+    p.xp = ox + e; p.yp = oy + e; p.zp = oz + e;
+    p.xm = ox - e; p.ym = oy - e; p.zm = oz - e;
+    return p;
 }
 
 /* true and t,u,v written when the triangle is hit inside (tNear, tFar] */
@@ -167,6 +185,7 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
     st.init();
     int32_t cur = 0;
     const float4* __restrict__ nodes = bvh.nodes;
+    const RayPad pad = ray_pad(ox, oy, oz, nodes[7].x);
     const float4* __restrict__ tris = bvh.tris;
     for (;;)
     {
@@ -183,9 +202,9 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
 #pragma unroll
             for (int k = 0; k < 4; ++k)
             {
-                const float ax = (lx[k] - ox) * ix, bx = (hx[k] - ox) * ix;
-                const float ay = (ly[k] - oy) * iy, by = (hy[k] - oy) * iy;
-                const float az = (lz[k] - oz) * iz, bz = (hz[k] - oz) * iz;
+                const float ax = (lx[k] - pad.xp) * ix, bx = (hx[k] - pad.xm) * ix;
+                const float ay = (ly[k] - pad.yp) * iy, by = (hy[k] - pad.ym) * iy;
+                const float az = (lz[k] - pad.zp) * iz, bz = (hz[k] - pad.zm) * iz;
                 float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
                 float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
                 t1 = fminf(t1, h.t);

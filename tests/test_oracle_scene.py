@@ -53,6 +53,18 @@ def test_synthetic_scene_bvh_equals_brute_force():
     assert (p_a == p_b).all() and (bits(tuv_a) == bits(tuv_b)).all()
 
 
+def test_bvh_never_culls_what_the_triangle_test_accepts(cornell):
+    """secondary rays starting 1e-5 off a surface: the fp32 test accepts a few "hits" a hair BEHIND the origin
+    whose t rounds to +5e-7 (the contract is the fp32 test over all triangles); the per-ray box padding must keep
+    the BVH walk from culling them -- found on the GPU with 2-triangle leaves, hence the large ray count"""
+    for sc in (cornell, scenes.synthetic_scene(target_tris=3000, seed=7, extent=20.0, emissive_attempts=8)):
+        o = OracleScene(sc.desc, accel=1)
+        ro, rd = scenes.surface_rays(sc, 200000 if sc is cornell else 20000, seed=12, offset=1e-5)
+        p_a, tuv_a = o.intersect_raw(ro, rd)
+        p_b, tuv_b = o.intersect_raw(ro, rd, brute=True)
+        assert (p_a == p_b).all() and (bits(tuv_a) == bits(tuv_b)).all()
+
+
 def test_flatten_matches_oracle_restatement():
     lib = load_oracle()
     rng = np.random.default_rng(2)
