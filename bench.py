@@ -164,6 +164,13 @@ def main():
         crays = max(crays, 1)
         b_ray = 48.0 + 128.0 * nodes / crays + 48.0 * tris / crays
         achieved = rays * b_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        # HBM-side bytes per traversal launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+        # rocprofv3 runs of this same command: scripts/profile_bench.sh -> profiles/traffic.json); counters cannot
+        # be read inside this process, so the figure is the committed measurement of this workload, or null
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = (json.load(open(tpath)).get(args.workload) or {}).get("bytes_per_launch")
         out = {
             "metric": "Mrays/sec (incoherent, per GPU + node) and spp/sec at 1080p; % HBM BW peak",
             "value": rays_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,7 +185,8 @@ def main():
             "bvh_build_ms": info.bvhBuildMs, "scene_setup_ms": info.sceneSetupMs,
             "device_ms_per_step": total_ms / args.steps, "traversal_ms_per_step": trace_ms / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": rays / (args.steps * 2 * wl["bounces"]) * b_ray,
                          "bytes_per_ray": b_ray, "nodes_per_ray": nodes / crays, "tris_per_ray": tris / crays, "max_nodes_one_ray": worst,
                          "rays_per_launch": rays / (args.steps * 2 * wl["bounces"]),
                          "avg_launch_ms": trace_ms / (args.steps * 2 * wl["bounces"])},
