@@ -119,7 +119,7 @@ static int scene_build_bvh(PimScene* s)
         std::string why;
         if ((rc = bvh_validate(&s->bvh, g_lib.stream, &why))) { set_error("BVH validation failed: %s", why.c_str()); return rc; }
     }
-    if (s->bvh.maxDepthDev) PT_HIP(hipMemcpy(&s->bvhDepth, s->bvh.maxDepthDev, 4, hipMemcpyDeviceToHost));
+    s->bvhDepth = s->bvh.depth;
     return PIMGPU_OK;
 }
 

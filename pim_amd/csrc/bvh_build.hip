@@ -2,15 +2,15 @@
  * bvh_build.hip -- GPU BVH build; replaces rtcCommitScene (rendering/path_tracer.c:618-690,
  * RTC_GEOMETRY_TYPE_TRIANGLE, identity index buffer, primID*3 == iVert).
  *
- * Pipeline, all on one stream, no host round trip:
+ * Pipeline, all on one stream (the collapse reads its level table back every 8 levels):
  *   tri_bounds  : per-triangle padded AABB + scene centroid bounds (wave reduce + ordered-uint atomics)
  *   morton      : 63-bit Morton code of the centroid (21 bits per axis)
  *   radix sort  : hand-written 8-bit LSD radix sort of (u64 key, u32 triangle) pairs,
  *                 wave64 ballot-match ranking (stable), 3 kernels per pass
  *   karras      : LBVH topology from the sorted codes (Karras 2012), one lane per inner node
  *   refit       : bottom-up AABB union, second arriver at a node proceeds (agent-scope acq_rel atomic)
- *   collapse    : subtrees with <= PT_LEAF_MAX triangles become one leaf; every other level of the
- *                 binary tree is folded away -> 4-wide nodes of 128 B (layout: pt_device.h)
+ *   collapse    : top-down greedy SAH collapse into 4-wide nodes of 128 B (layout: pt_device.h), compact and
+ *                 breadth-first; subtrees with <= PT_LEAF_MAX triangles become one leaf
  *   emit_tris   : triangles copied in leaf order (3 float4 each, primID in p0.w)
  *
  * The closest-hit contract (lowest primID among equal t, exact fp32 watertight test per lane)
@@ -18,12 +18,14 @@
  * which the padded triangle boxes guarantee.
  */
 #include "pt_host.h"
+#include <algorithm>
 
 namespace pt {
 
 static constexpr int kSortThreads = 256;
 static constexpr int kSortRounds = 8;                      /* keys per thread */
 static constexpr int kSortTile = kSortThreads * kSortRounds;
+static constexpr int kMaxWideLevels = 120;                  /* the binary LBVH is at most 64 + 32 deep */
 
 __device__ __forceinline__ uint32_t float_to_ordered(float f)
 {
@@ -293,22 +295,6 @@ __global__ __launch_bounds__(256) void k_refit(int32_t n, const uint32_t* __rest
     }
 }
 
-/* depth parity of every inner node (root = even).  Even nodes that are not collapsed into a leaf
- * become 4-wide nodes. */
-__global__ __launch_bounds__(256) void k_depth(int32_t n, const int32_t* __restrict__ parent, uint8_t* __restrict__ odd, int32_t* __restrict__ maxDepth)
-{
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int32_t depth = 0;
-    if (i < n - 1)
-    {
-        int32_t p = parent[i];
-        while (p >= 0) { ++depth; p = parent[p]; }
-        odd[i] = (uint8_t)(depth & 1);
-    }
-    for (int o = 32; o > 0; o >>= 1) depth = max(depth, __shfl_xor(depth, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(maxDepth, depth);
-}
-
 struct WideSlot { float lo[3], hi[3]; int32_t child; };
 
 __device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint32_t* __restrict__ vals,
@@ -334,40 +320,95 @@ __device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint3
     s->hi[0] = hi.x; s->hi[1] = hi.y; s->hi[2] = hi.z;
 }
 
-__global__ __launch_bounds__(256) void k_emit_wide(int32_t n, const uint32_t* __restrict__ vals,
+/*
+ * Collapse of the binary tree into 4-wide nodes, top down, one launch per level of the WIDE tree.
+ * A wide node starts from the two children of its binary node and keeps opening the child with the
+ * largest surface area (the greedy SAH collapse) until it has 4 slots; subtrees of <= PT_LEAF_MAX
+ * triangles are leaves, and slots still free at the end are used to split such leaves into smaller ones
+ * (tighter boxes for free).  Wide nodes are allocated level by level from one counter, so the array is
+ * compact and breadth-first: node w of level L sits in [snap[L], snap[L+1]), wideSrc[w] is its binary node.
+ */
+struct Cand { int32_t id; int32_t count; float area; };
+
+__device__ __forceinline__ Cand cand_of(int32_t c, int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
+    const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast)
+{
+    float4 lo, hi; Cand k; k.id = c;
+    if (c >= n - 1) { const uint32_t t = vals[c - (n - 1)]; lo = triLo[t]; hi = triHi[t]; k.count = 1; }
+    else { lo = nodeLo[c]; hi = nodeHi[c]; k.count = rangeLast[c] - rangeFirst[c] + 1; }
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    k.area = dx * dy + dy * dz + dz * dx;
+    return k;
+}
+
+__global__ void k_collapse_begin(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_t* __restrict__ vals,
     const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
     const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
     const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast,
-    const uint8_t* __restrict__ odd, float4* __restrict__ wide)
+    int32_t* __restrict__ wideSrc, const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter,
+    float4* __restrict__ wide)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    if (odd[i]) return;
-    if (i != 0 && (rangeLast[i] - rangeFirst[i] + 1) <= PT_LEAF_MAX) return;      /* collapsed into a leaf */
+    const int32_t begin = snap[0], end = snap[1];
+    if (begin + (int32_t)(blockIdx.x * blockDim.x) >= end) return;          /* whole block beyond the level */
+    const int32_t w = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const bool active = w < end;
+    Cand cd[4]; int ns = 0;
+    if (active)
+    {
+        const int32_t src = wideSrc[w];
+        cd[0] = cand_of(child0[src], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+        cd[1] = cand_of(child1[src], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+        ns = 2;
+        /* pass 0 opens inner subtrees (count > PT_LEAF_MAX), pass 1 spends leftover slots on splitting leaves */
+        for (int pass = 0; pass < 2; ++pass)
+        {
+            while (ns < 4)
+            {
+                int best = -1; float bestArea = -1.0f;
+                for (int k = 0; k < ns; ++k)
+                {
+                    const bool open = pass == 0 ? (cd[k].count > PT_LEAF_MAX) : (cd[k].count > 1);
+                    if (open && cd[k].area > bestArea) { best = k; bestArea = cd[k].area; }
+                }
+                if (best < 0) break;
+                const int32_t c = cd[best].id;
+                cd[best] = cand_of(child0[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+                cd[ns++] = cand_of(child1[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+            }
+        }
+    }
+    /* allocate the wide children of the whole wave with one atomic */
+    int need = 0;
+    for (int k = 0; k < ns; ++k) need += (cd[k].count > PT_LEAF_MAX) ? 1 : 0;
+    int incl = need;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
+    const int total = __shfl(incl, 63, 64);
+    int32_t base = 0;
+    if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(nodeCounter, total);
+    base = __shfl(base, 63, 64);
+    if (!active) return;
+    int32_t next = base + incl - need;
     WideSlot slot[4];
-    int ns = 0;
-    const int32_t cs[2] = { child0[i], child1[i] };
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 4; ++k)
     {
-        const int32_t c = cs[k];
-        const bool inner = (c < n - 1) && ((rangeLast[c] - rangeFirst[c] + 1) > PT_LEAF_MAX);
-        if (inner)
+        if (k >= ns)
         {
-            wide_slot_from(child0[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
-            wide_slot_from(child1[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
+            for (int a = 0; a < 3; ++a) { slot[k].lo[a] = __builtin_inff(); slot[k].hi[a] = -__builtin_inff(); }
+            slot[k].child = PT_BVH_EMPTY;
+            continue;
         }
-        else
-        {
-            wide_slot_from(c, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[ns++]);
-        }
+        wide_slot_from(cd[k].id, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[k]);
+        if (cd[k].count > PT_LEAF_MAX) { slot[k].child = next; wideSrc[next] = cd[k].id; ++next; }
     }
-    for (; ns < 4; ++ns)
-    {
-        for (int a = 0; a < 3; ++a) { slot[ns].lo[a] = __builtin_inff(); slot[ns].hi[a] = -__builtin_inff(); }
-        slot[ns].child = PT_BVH_EMPTY;
-    }
-    float4* q = wide + (size_t)i * 8;
+    float4* q = wide + (size_t)w * 8;
     q[0] = make_float4(slot[0].lo[0], slot[1].lo[0], slot[2].lo[0], slot[3].lo[0]);
     q[1] = make_float4(slot[0].lo[1], slot[1].lo[1], slot[2].lo[1], slot[3].lo[1]);
     q[2] = make_float4(slot[0].lo[2], slot[1].lo[2], slot[2].lo[2], slot[3].lo[2]);
@@ -378,7 +419,7 @@ __global__ __launch_bounds__(256) void k_emit_wide(int32_t n, const uint32_t* __
     /* node 0's spare quad carries the largest |coordinate| of the scene: the traversal pads every box by a
      * per-ray epsilon proportional to (|origin| + this), see traverse.h */
     float maxAbs = 0.0f;
-    if (i == 0)
+    if (w == 0)
     {
         const float4 rl = nodeLo[0], rh = nodeHi[0];
         maxAbs = fmaxf(fmaxf(fmaxf(fabsf(rl.x), fabsf(rl.y)), fabsf(rl.z)), fmaxf(fmaxf(fabsf(rh.x), fabsf(rh.y)), fabsf(rh.z)));
@@ -447,7 +488,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     const size_t oChild0 = take(4 * (size_t)cap), oChild1 = take(4 * (size_t)cap);
     const size_t oParent = take(4 * (size_t)(2 * cap)), oFirst = take(4 * (size_t)cap), oLast = take(4 * (size_t)cap);
     const size_t oNodeLo = take(sizeof(float4) * cap), oNodeHi = take(sizeof(float4) * cap);
-    const size_t oFlags = take(4 * (size_t)cap), oOdd = take((size_t)cap), oBounds = take(64), oDepth = take(64);
+    const size_t oFlags = take(4 * (size_t)cap), oWideSrc = take(4 * (size_t)cap), oBounds = take(64), oSnap = take(4 * (kMaxWideLevels + 8));
     const size_t need = off;
     if (b->capacityTris < cap || b->scratchBytes < need)
     {
@@ -465,14 +506,14 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     int32_t* child0 = (int32_t*)(s + oChild0); int32_t* child1 = (int32_t*)(s + oChild1);
     int32_t* parent = (int32_t*)(s + oParent); int32_t* rangeFirst = (int32_t*)(s + oFirst); int32_t* rangeLast = (int32_t*)(s + oLast);
     float4* nodeLo = (float4*)(s + oNodeLo); float4* nodeHi = (float4*)(s + oNodeHi);
-    uint32_t* flags = (uint32_t*)(s + oFlags); uint8_t* odd = (uint8_t*)(s + oOdd);
-    uint32_t* bounds = (uint32_t*)(s + oBounds); int32_t* depth = (int32_t*)(s + oDepth);
+    uint32_t* flags = (uint32_t*)(s + oFlags); int32_t* wideSrc = (int32_t*)(s + oWideSrc);
+    uint32_t* bounds = (uint32_t*)(s + oBounds);
+    int32_t* snap = (int32_t*)(s + oSnap); int32_t* nodeCounter = snap + kMaxWideLevels + 4;
 
     b->triCount = n;
-    b->nodeCount = n > 1 ? n - 1 : 1;
-    b->maxDepthDev = depth;
+    b->nodeCount = 1;
+    b->depth = 0;
     const int grid = (cap + 255) / 256;
-    hipMemsetAsync(depth, 0, 4, stream);
     k_bounds_init<<<1, 64, 0, stream>>>(bounds);
     if (n > 0) k_tri_bounds<<<grid, 256, 0, stream>>>(positionsDev, n, triLo, triHi, bounds);
     if (n <= PT_LEAF_MAX)
@@ -495,9 +536,33 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     k_karras<<<grid, 256, 0, stream>>>(kin, n, child0, child1, parent, rangeFirst, rangeLast);
     hipMemsetAsync(flags, 0, 4 * (size_t)n, stream);
     k_refit<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, child0, child1, parent, nodeLo, nodeHi, flags);
-    k_depth<<<grid, 256, 0, stream>>>(n, parent, odd, depth);
-    k_emit_wide<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, nodeLo, nodeHi, child0, child1, rangeFirst, rangeLast, odd, b->nodes);
     k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, vin, n, b->tris);
+    /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
+     * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
+    k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc);
+    int32_t hostSnap[kMaxWideLevels + 2];
+    int level = 0;
+    bool done = false;
+    while (!done)
+    {
+        if (level >= kMaxWideLevels) { set_error("BVH collapse: more than %d levels", kMaxWideLevels); return PIMGPU_E_STATE; }
+        const int batchEnd = std::min(level + 8, kMaxWideLevels);
+        for (; level < batchEnd; ++level)
+        {
+            /* level L holds at most 4^L nodes and never more than the binary tree has inner nodes */
+            int64_t most = level < 15 ? ((int64_t)1 << (2 * level)) : (int64_t)n;
+            most = std::min<int64_t>(most, n);
+            k_collapse_level<<<(int)((most + 255) / 256), 256, 0, stream>>>(n, vin, triLo, triHi, nodeLo, nodeHi, child0, child1,
+                rangeFirst, rangeLast, wideSrc, snap + level, nodeCounter, b->nodes);
+            if (hipMemcpyAsync(snap + level + 2, nodeCounter, 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return PIMGPU_E_DEVICE;
+        }
+        if (hipMemcpyAsync(hostSnap, snap, sizeof(int32_t) * (size_t)(level + 2), hipMemcpyDeviceToHost, stream) != hipSuccess) return PIMGPU_E_DEVICE;
+        if (hipStreamSynchronize(stream) != hipSuccess) return PIMGPU_E_DEVICE;
+        for (int l = 0; l <= level; ++l)
+        {
+            if (hostSnap[l + 1] == hostSnap[l]) { done = true; b->depth = l; b->nodeCount = hostSnap[l]; break; }
+        }
+    }
     return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
 }
 

@@ -20,12 +20,12 @@ struct BvhStorage
     int32_t capacityTris = 0;
     int32_t triCount = 0;
     int32_t nodeCount = 0;
-    int32_t* maxDepthDev = nullptr;     /* inside scratch: depth of the binary tree of the last build */
+    int32_t depth = 0;                  /* levels of the 4-wide tree of the last build */
     void release();
     DBvh view() const { DBvh b; b.nodes = nodes; b.tris = tris; b.nodeCount = nodeCount; b.triCount = triCount; return b; }
 };
 
-/* bvh_build.hip: full (re)build from device positions (float4[3*triCount]); asynchronous on stream */
+/* bvh_build.hip: full (re)build from device positions (float4[3*triCount]) on stream; returns with the stream drained */
 int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream_t stream);
 
 int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why);
