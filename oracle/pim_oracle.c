@@ -594,21 +594,54 @@ static void SetupEmissives(OrcScene* s, int32_t attempts, int threads)
     free(pdfs);
 }
 
-/* RtcPointQuery + RtcPointQueryFn, pt.c:555-616: nearest triangle inside the query radius */
+/* RtcPointQuery + RtcPointQueryFn, pt.c:555-616: nearest triangle inside the query radius.
+ * The answer is min{ d(tri) : d(tri) < radius }, which does not depend on the visiting order, so the
+ * walk over the BVH (accel = 1: boxes farther than a slightly enlarged radius are skipped) and the
+ * loop over all triangles (accel = 0) return the same float. */
+static inline float point_tri_distance(const OrcScene* s, int32_t i, v4 pt)
+{
+    const v4* p = s->positions + i * 3;
+    return o_abs(sdTriangle3D(p[0], p[1], p[2], pt));
+}
+
 static float point_query_distance(const OrcScene* s, v4 pt)
 {
     float best = ORC_RCP_EPS;
-    float radius = pt.w;
+    const float radius = pt.w;
     const int32_t triCount = s->vertCount / 3;
+    if (s->accel && s->nodes)
+    {
+        const float prune = radius * 1.001f + 1e-6f;
+        const float prune2 = prune * prune;
+        const float q[3] = { pt.x, pt.y, pt.z };
+        int32_t stack[128]; int sp = 0;
+        stack[sp++] = 0;
+        while (sp)
+        {
+            const OrcNode* n = &s->nodes[stack[--sp]];
+            float d2 = 0.0f;
+            for (int a = 0; a < 3; ++a)
+            {
+                float e = fmaxf(fmaxf(n->lo[a] - q[a], q[a] - n->hi[a]), 0.0f);
+                d2 += e * e;
+            }
+            if (!(d2 <= prune2)) continue;
+            if (n->count)
+            {
+                for (int32_t k = 0; k < n->count; ++k)
+                {
+                    float d = point_tri_distance(s, s->triIndex[n->first + k], pt);
+                    if (d < radius && d < best) best = d;
+                }
+            }
+            else if (n->left >= 0) { stack[sp++] = n->left; stack[sp++] = n->right; }
+        }
+        return best;
+    }
     for (int32_t i = 0; i < triCount; ++i)
     {
-        const v4* p = s->positions + i * 3;
-        /* cheap reject on the triangle's bounds against the query sphere, like Embree's culling */
-        float lo[3] = { fminf(p[0].x, fminf(p[1].x, p[2].x)), fminf(p[0].y, fminf(p[1].y, p[2].y)), fminf(p[0].z, fminf(p[1].z, p[2].z)) };
-        float hi[3] = { fmaxf(p[0].x, fmaxf(p[1].x, p[2].x)), fmaxf(p[0].y, fmaxf(p[1].y, p[2].y)), fmaxf(p[0].z, fmaxf(p[1].z, p[2].z)) };
-        if (pt.x < lo[0] - radius || pt.x > hi[0] + radius || pt.y < lo[1] - radius || pt.y > hi[1] + radius || pt.z < lo[2] - radius || pt.z > hi[2] + radius) continue;
-        float d = o_abs(sdTriangle3D(p[0], p[1], p[2], pt));
-        if (d < radius && d < best) { best = d; radius = o_min(radius, d); }
+        float d = point_tri_distance(s, i, pt);
+        if (d < radius && d < best) best = d;
     }
     return best;
 }

@@ -1,0 +1,87 @@
+"""-m gpu: parity at BASELINE config 3's scene size -- the 1M-triangle synthetic scene (seed 1234, 100 m).
+
+The oracle walks its own binned-SAH BVH here (brute force is O(rays x 1M)); that walk is pinned bit-for-bit
+against the brute-force loop on the smaller scenes of tests/test_oracle_scene.py.  Checked BIT-EXACT:
+  - scene set-up: emissive maps, the 49^3-cell light grid's Dist1D lengths / pdf / cdf (RtcPointQuery walk,
+    16 probe rays and 16 x E occlusion rays per cell);
+  - >= 1M primary (camera) and >= 1M secondary (surface + 1e-5 N, shuffled) closest hits, SURVEY 8(d) gate (i);
+  - an 8-bounce image (rays, autofocus, light histograms included)."""
+import numpy as np
+import pytest
+
+from pim_amd import api, scenes
+from tests.gpu_util import gpu_init, assert_bits_equal
+from tests.util import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    gpu_init()
+    sc = scenes.synthetic_scene(target_tris=1000000, seed=1234, extent=100.0, emissive_attempts=16)
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    yield sc, g, o
+    g.close()
+
+
+def test_1m_scene_setup_bit_exact(big):
+    sc, g, o = big
+    gi, oi = g.info(), o.info()
+    assert gi.triCount == oi.triCount == sc.tri_count and abs(sc.tri_count - 1000000) <= 2208
+    assert gi.emissiveCount == oi.emissiveCount and list(gi.gridSize) == list(oi.gridSize) and gi.activeCells == oi.activeCells
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("vertToEmit", "emitToVert", "cellLength", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k)
+
+
+def _primary_rays(sc, n, seed):
+    cam = scenes.synthetic_camera(100.0)
+    W = 1536; H = (n + W - 1) // W
+    rng = np.random.default_rng(seed)
+    px = (np.arange(W * H) % W + rng.random(W * H)) / W * 2.0 - 1.0
+    py = (np.arange(W * H) // W + rng.random(W * H)) / H * 2.0 - 1.0
+    q = np.array(cam.rotation, np.float32)
+    eye = np.array(cam.position, np.float32)[:3]
+    def rot(v):
+        u = q[:3]; s = q[3]
+        return 2.0 * np.dot(u, v) * u + (s * s - np.dot(u, u)) * v + 2.0 * s * np.cross(u, v)
+    fwd, right, up = rot(np.array([0, 0, -1.0], np.float32)), rot(np.array([1.0, 0, 0], np.float32)), rot(np.array([0, 1.0, 0], np.float32))
+    d = fwd[None, :] + (px * (W / H))[:, None] * right[None, :] + py[:, None] * up[None, :]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ro = np.zeros((W * H, 4), np.float32); rd = np.zeros((W * H, 4), np.float32)
+    ro[:, :3] = eye; rd[:, :3] = d
+    return ro, rd
+
+
+def test_1m_scene_two_million_hits_bit_exact(big):
+    sc, g, o = big
+    for name, (ro, rd) in (("primary", _primary_rays(sc, 1 << 20, 3)), ("secondary", scenes.surface_rays(sc, 1 << 20, seed=4, offset=1e-5))):
+        assert ro.shape[0] >= 1 << 20
+        hg, ho = g.intersect(ro, rd), o.intersect(ro, rd)
+        for field in ("type", "iVert", "flags", "wuvt", "normal"):
+            assert_bits_equal(hg[field], ho[field], name + " " + field)
+        assert (hg["type"] != api.HIT_NOTHING).mean() > 0.99
+
+
+def test_1m_scene_image_bit_exact(big):
+    sc, g, o = big
+    W, H = 480, 270
+    cam = scenes.synthetic_camera(100.0)
+    t = api.Trace(W, H)
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dg, do = scenes.default_dof(), scenes.default_dof()
+    for s in range(2):
+        p = scenes.trace_params(s, seed=23, max_bounces=8)
+        t.trace(g, cam, dg, p)
+        so = o.trace_image(img, W, H, cam, do, p)
+        sg = t.stats()
+        assert (sg.extensionRays, sg.shadowRays, sg.otherRays, sg.paths) == (so.extensionRays, so.shadowRays, so.otherRays, so.paths)
+        assert dg.focalLength == do.focalLength
+    color, albedo, normal = t.download()
+    assert_bits_equal(color, img[0], "color"); assert_bits_equal(albedo, img[1], "albedo"); assert_bits_equal(normal, img[2], "normal")
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("live", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k)
+    t.close()
