@@ -262,6 +262,18 @@ int pimgpu_raygen(PimScene* scene, const float* origin, int32_t count,
     uint32_t sampleIndex, uint32_t seed, int32_t maxBounces,
     float* colors, float* directions);
 
+/* Cubemap_Bake (rendering/cubemap.c:130-190, BakeFn :138-160): one path per cube-face texel from `origin`
+ * through Cubemap_CalcDir(size, face, coord, f2_tent(Xi)) (cubemap.h:190-207), blended into the six host faces
+ * (float3[size*size] each, Cubemap.color[face], cubemap.h:28-34) as lerp(old, result.color, weight).
+ * Texel i = face*size^2 + y*size + x owns the stream Pcg4(i, sampleIndex, seed, k). */
+int pimgpu_cubemap_bake(PimScene* scene, float* const faces[6], int32_t size, const float* origin, float weight,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces);
+/* AmbCube_Bake (math/ambcube.c:5-32): Pt_RayGen(origin, samples) then AmbCube_Fit (ambcube.h:45-67) over the
+ * samples IN ORDER with w = 6/(1+samples)/(1+prevSampleCount).  cube: AmbCube_t, 6 float4 (math/types.h:513-517),
+ * host, updated in place; *newSampleCount = prevSampleCount + 1. */
+int pimgpu_ambcube_bake(PimScene* scene, float* cube, const float* origin, int32_t samples, int32_t prevSampleCount,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, int32_t* newSampleCount);
+
 /* ---- image --------------------------------------------------------------- */
 
 /* PtTrace_New / PtTrace_Del (path_tracer.c:1117-1139): zeroed device buffers */

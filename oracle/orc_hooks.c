@@ -84,6 +84,16 @@ HOOK(UvBilinearClamp_4x4)
 }
 HOOK(Cubemap_CalcUv) { v2 uv; int f = Cubemap_CalcUv(F3(in, 0, 0.0f), &uv); out[0] = (uint32_t)f; PF(out, 1, uv.x); PF(out, 2, uv.y); }
 
+HOOK(f2_tent) { v2 r = f2_tent(o2(F(in, 0), F(in, 1))); PF(out, 0, r.x); PF(out, 1, r.y); }
+HOOK(Cubemap_CalcDir) { v4 d = Cubemap_CalcDir((int32_t)in[0], (int)in[1], (int32_t)in[2], (int32_t)in[3], o2(F(in, 4), F(in, 5))); PF(out, 0, d.x); PF(out, 1, d.y); PF(out, 2, d.z); }
+HOOK(AmbCube_Fit)
+{
+    OrcAmbCube c;
+    for (int k = 0; k < 6; ++k) c.Values[k] = o4(F(in, k * 4), F(in, k * 4 + 1), F(in, k * 4 + 2), F(in, k * 4 + 3));
+    AmbCube_Fit(&c, F(in, 24), F3(in, 25, 0.0f), o4(F(in, 28), F(in, 29), F(in, 30), F(in, 31)));
+    for (int k = 0; k < 6; ++k) { PF(out, k * 4, c.Values[k].x); PF(out, k * 4 + 1, c.Values[k].y); PF(out, k * 4 + 2, c.Values[k].z); PF(out, k * 4 + 3, c.Values[k].w); }
+}
+
 /* Grid, math/grid.h:8-49 (same arithmetic as pim_oracle.c's grid_*) */
 HOOK(Grid)
 {

@@ -611,6 +611,44 @@ ORC_INL int Cubemap_CalcUv(v4 dir, v2* uvOut)
     return face;
 }
 
+/* f2_tent, math/float2_funcs.h:630-636.  As written in the reference: the y lane's upper branch reads
+ * Xi.x AFTER it was mapped (2 - Xi.x, not 2 - Xi.y); restated as is, the golden vectors pin it. */
+ORC_INL v2 f2_tent(v2 Xi)
+{
+    Xi = o2(Xi.x * 2.0f, Xi.y * 2.0f);
+    Xi.x = Xi.x < 1.0f ? sqrtf(Xi.x) - 1.0f : 1.0f - sqrtf(2.0f - Xi.x);
+    Xi.y = Xi.y < 1.0f ? sqrtf(Xi.y) - 1.0f : 1.0f - sqrtf(2.0f - Xi.x);
+    return Xi;
+}
+
+/* Cubemap_CalcDir, rendering/cubemap.h:190-207 (BilinearInvert / LinearInvert rendering/sampler.h:192-236,
+ * f2_snorm math/float2_funcs.h:620, Cubemap_kForwards / kRights / kUps rendering/cubemap.c:14-42) */
+ORC_INL v4 Cubemap_CalcDir(int32_t size, int face, int32_t cx, int32_t cy, v2 Xi)
+{
+    static const float kFwd[6][3] = { {1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1} };
+    static const float kUps[6][3] = { {0,1,0},{0,1,0},{0,0,-1},{0,0,-1},{0,1,0},{0,1,0} };
+    static const float kRights[6][3] = { {0,0,-1},{0,0,1},{1,0,0},{-1,0,0},{1,0,0},{-1,0,0} };
+    v2 uv = o2((float)cx / (float)(size - 1), (float)cy / (float)(size - 1));
+    const float rcp = 1.0f / size;
+    Xi = o2(Xi.x * rcp, Xi.y * rcp);
+    uv = o2_add(uv, Xi);
+    uv = o2(uv.x * 2.0f - 1.0f, uv.y * 2.0f - 1.0f);
+    return proj_dir(o4(kRights[face][0], kRights[face][1], kRights[face][2], 0.0f), o4(kUps[face][0], kUps[face][1], kUps[face][2], 0.0f),
+        o4(kFwd[face][0], kFwd[face][1], kFwd[face][2], 0.0f), o2(1.0f, 1.0f), uv);
+}
+
+/* AmbCube_Fit, math/ambcube.h:45-67 (AmbCube_t math/types.h:513-517) */
+typedef struct { v4 Values[6]; } OrcAmbCube;
+ORC_INL void AmbCube_Fit(OrcAmbCube* c, float weight, v4 dir, v4 rad)
+{
+    const int fx = dir.x > 0.0f, fy = dir.y > 0.0f, fz = dir.z > 0.0f;
+    dir = o4_mul(dir, dir);
+    dir = o4_muls(dir, weight);
+    v4* vx = &c->Values[fx ? 0 : 1]; *vx = o4_lerps(*vx, rad, dir.x);
+    v4* vy = &c->Values[fy ? 2 : 3]; *vy = o4_lerps(*vy, rad, dir.y);
+    v4* vz = &c->Values[fz ? 4 : 5]; *vz = o4_lerps(*vz, rad, dir.z);
+}
+
 /* ---- geometry helpers: math/area.h:28, math/sdf.h:158-189 ---- */
 ORC_INL float TriArea3D(v4 A, v4 B, v4 C) { return 0.5f * o4_length3(o4_cross3(o4_sub(B, A), o4_sub(C, A))); }
 ORC_INL float sdTriangle3D(v4 a, v4 b, v4 c, v4 p)

@@ -30,6 +30,7 @@
 #define TAG_BAKE_PT  0xA511E9B3u
 #define TAG_EMIT     0x454D4954u
 #define TAG_GRID     0x47524944u
+#define TAG_CUBE     0x43554245u
 
 typedef struct { float* pdf; float* cdf; uint32_t* live; } OrcDistArrays;
 
@@ -1539,6 +1540,53 @@ void orc_raygen(OrcScene* s, const float* origin, int32_t count, uint32_t sample
     t.s = s; t.sampleIndex = sampleIndex; t.seed = seed; t.maxBounces = maxBounces;
     t.origin = o4(origin[0], origin[1], origin[2], origin[3]); t.colors = colors; t.directions = directions;
     orc_parallel_for(rays_fn, &t, count, threads);
+}
+
+/* Cubemap_Bake + BakeFn, rendering/cubemap.c:130-190: one path per cube-face texel through a tent-jittered
+ * direction, blended into color[face][texel] with f3_lerpvs(old, new, weight).  D1: one stream per texel. */
+typedef struct { OrcScene* s; float* const* faces; int32_t size; v4 origin; float weight; uint32_t sampleIndex, seed; int32_t maxBounces; } CubeTask;
+static void cube_fn(void* user, int64_t begin, int64_t end, int tid)
+{
+    (void)tid;
+    CubeTask* t = (CubeTask*)user;
+    const int32_t size = t->size, flen = size * size;
+    for (int64_t i = begin; i < end; ++i)
+    {
+        OrcCtx ctx; memset(&ctx, 0, sizeof(ctx));
+        ctx.rng = pcg4((uint32_t)i, t->sampleIndex, t->seed, TAG_CUBE);
+        int32_t face = (int32_t)(i / flen), fi = (int32_t)(i % flen);
+        v2 Xi = f2_tent(rng_f2(&ctx.rng));
+        v4 dir = Cubemap_CalcDir(size, face, fi % size, fi / size, Xi);
+        PimResult r = Pt_TraceRay(&ctx, t->s, t->origin, dir, t->maxBounces);
+        float* c = t->faces[face] + (size_t)fi * 3;
+        for (int k = 0; k < 3; ++k) c[k] = c[k] + (r.color[k] - c[k]) * t->weight;        /* f3_lerpvs, float3_funcs.h:373 */
+    }
+}
+
+void orc_cubemap_bake(OrcScene* s, float* const faces[6], int32_t size, const float* origin, float weight,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, int threads)
+{
+    if (size <= 0) return;                                                                /* cubemap.c:172 */
+    CubeTask t; memset(&t, 0, sizeof(t));
+    t.s = s; t.faces = faces; t.size = size; t.origin = o4(origin[0], origin[1], origin[2], origin[3]); t.weight = weight;
+    t.sampleIndex = sampleIndex; t.seed = seed; t.maxBounces = maxBounces;
+    orc_parallel_for(cube_fn, &t, (int64_t)size * size * 6, threads);
+}
+
+/* AmbCube_Bake, math/ambcube.c:5-32: Pt_RayGen + the serial fit over the samples in order */
+int32_t orc_ambcube_bake(OrcScene* s, float* cube, const float* origin, int32_t samples, int32_t prevSampleCount,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, int threads)
+{
+    float* colors = (float*)malloc(sizeof(float) * 4 * (size_t)(samples + 1));
+    float* directions = (float*)malloc(sizeof(float) * 4 * (size_t)(samples + 1));
+    orc_raygen(s, origin, samples, sampleIndex, seed, maxBounces, colors, directions, threads);
+    OrcAmbCube c; memcpy(&c, cube, sizeof(c));
+    float w = 6.0f / (1.0f + samples);
+    w = w / (1.0f + prevSampleCount);
+    for (int32_t i = 0; i < samples; ++i) AmbCube_Fit(&c, w, ld4(directions, i), ld4(colors, i));
+    memcpy(cube, &c, sizeof(c));
+    free(colors); free(directions);
+    return prevSampleCount + 1;
 }
 
 /* CalculateDof, pt.c:2418-2452 */

@@ -48,6 +48,7 @@
 #include "common/random.h"
 #include "rendering/sampler.h"
 #include "rendering/cubemap.h"
+#include "math/ambcube.h"
 
 /* rendering/lightmap.h cannot be included (it pulls vulkan/vkr.h -> <volk/volk.h>, an empty
  * submodule); the five lobe axes it defines (lightmap.h:14-21) are input DATA of the
@@ -318,6 +319,33 @@ int main(int argc, char** argv)
     end("box_from_pts", 32, 24, 6);
 
     /* patch record count */
+    /* ---- callers of Pt_TraceRay besides the image: Cubemap_Bake (cubemap.c:130-190), AmbCube_Bake (ambcube.c:5-32) ---- */
+    begin(); for (int i = 0; i < N; ++i) { float2 Xi = { rnd(), rnd() }; if (i < 4) { Xi.x = (i & 1) ? 0.5f : 0.0f; Xi.y = (i & 2) ? 0.5f : 0.0f; } float2 r = f2_tent(Xi); putf(Xi.x); putf(Xi.y); putf(r.x); putf(r.y); } end("f2_tent", N, 2, 2);
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        i32 size = (i & 1) ? 64 : 2 + (i32)(nextu() % 30u);
+        i32 face = (i32)(nextu() % 6u);
+        int2 coord = { (i32)(nextu() % (u32)size), (i32)(nextu() % (u32)size) };
+        float2 Xi = { rnds(-1, 1), rnds(-1, 1) };
+        float4 d = Cubemap_CalcDir(size, (Cubeface)face, coord, Xi);
+        putu((u32)size); putu((u32)face); putu((u32)coord.x); putu((u32)coord.y); putf(Xi.x); putf(Xi.y); PUT3(d);
+    }
+    end("Cubemap_CalcDir", N, 6, 3);
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        AmbCube_t c;
+        for (int k = 0; k < 6; ++k) c.Values[k] = f4_v(rnds(0, 4), rnds(0, 4), rnds(0, 4), rnds(0, 1));
+        float w = rnds(0.0f, 1.0f);
+        float4 dir = rndunit(); float4 rad = f4_v(rnds(0, 8), rnds(0, 8), rnds(0, 8), 0.0f);
+        for (int k = 0; k < 6; ++k) PUT4(c.Values[k]);
+        putf(w); PUT3(dir); PUT4(rad);
+        c = AmbCube_Fit(c, w, dir, rad);
+        for (int k = 0; k < 6; ++k) PUT4(c.Values[k]);
+    }
+    end("AmbCube_Fit", N, 32, 24);
+
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);
     fclose(s_out);

@@ -94,6 +94,7 @@ EXPORTS = [
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
+    "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
 ]
 
@@ -197,6 +198,25 @@ class Scene:
         check(self.lib.pimgpu_raygen(self.handle, _ptr(origin), C.c_int32(count), C.c_uint32(sampleIndex), C.c_uint32(seed),
               C.c_int32(maxBounces), _ptr(colors), _ptr(directions)), "pimgpu_raygen")
         return colors, directions
+
+    def cubemap_bake(self, faces, size, origin, weight, sampleIndex=0, seed=0, maxBounces=0):
+        """Cubemap_Bake (rendering/cubemap.c:162-190); faces: six float32 arrays of size*size*3, updated in place"""
+        arr = (C.c_void_p * 6)()
+        for f in range(6):
+            assert faces[f].dtype == np.float32 and faces[f].flags["C_CONTIGUOUS"] and faces[f].size == size * size * 3
+            arr[f] = faces[f].ctypes.data
+        origin = f32(origin)
+        check(self.lib.pimgpu_cubemap_bake(self.handle, arr, C.c_int32(size), _ptr(origin), C.c_float(weight), C.c_uint32(sampleIndex),
+              C.c_uint32(seed), C.c_int32(maxBounces)), "pimgpu_cubemap_bake")
+
+    def ambcube_bake(self, cube, origin, samples, prevSampleCount=0, sampleIndex=0, seed=0, maxBounces=0):
+        """AmbCube_Bake (math/ambcube.c:5-32); cube: float32[6,4] updated in place; returns the new sample count"""
+        assert cube.dtype == np.float32 and cube.flags["C_CONTIGUOUS"] and cube.size == 24
+        origin = f32(origin)
+        out = C.c_int32(0)
+        check(self.lib.pimgpu_ambcube_bake(self.handle, _ptr(cube), _ptr(origin), C.c_int32(samples), C.c_int32(prevSampleCount),
+              C.c_uint32(sampleIndex), C.c_uint32(seed), C.c_int32(maxBounces), C.byref(out)), "pimgpu_ambcube_bake")
+        return out.value
 
     def lightmap_bake(self, pages, lmSize, texelsPerMeter, timeSlice, spp, passIndex=0, seed=0, maxBounces=0,
                       texelBegin=0, texelEnd=-1):

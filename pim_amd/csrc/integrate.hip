@@ -273,17 +273,26 @@ __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, 
     path_start(ps, extO, extD, queue, i, ctx, ro, rd);
 }
 
-/* batched Pt_TraceRay: rays given (mode 0) or RayGenFn's uniform sphere directions (mode 1, pt.c:2596-2612) */
+/* batched Pt_TraceRay: rays given (ro != null), RayGenFn's uniform sphere directions (pt.c:2596-2612), or the
+ * tent-jittered cube-face directions of Cubemap_Bake's BakeFn (cubemap.c:138-160) when cubeSize > 0 */
 __global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, float4* extD, int32_t* queue,
     const float4* __restrict__ ro, const float4* __restrict__ rd, v4 origin, float4* __restrict__ directionsOut,
-    int32_t n, uint32_t sampleIndex, uint32_t seed)
+    int32_t n, uint32_t sampleIndex, uint32_t seed, int32_t cubeSize)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Ctx ctx = ctx_make();
-    ctx.rng = pcg4((uint32_t)i, sampleIndex, seed, PT_TAG_RAY);
+    ctx.rng = pcg4((uint32_t)i, sampleIndex, seed, cubeSize > 0 ? PT_TAG_CUBE : PT_TAG_RAY);
     v4 o, d;
     if (ro) { o = ld4(ro, i); d = ld4(rd, i); }
+    else if (cubeSize > 0)
+    {
+        const int32_t flen = cubeSize * cubeSize;
+        const int32_t face = i / flen, fi = i % flen;
+        const v2 Xi = f2_tent(Sample2D(ctx));
+        o = origin;
+        d = Cubemap_CalcDir(cubeSize, face, fi % cubeSize, fi / cubeSize, Xi);
+    }
     else
     {
         o = origin;
@@ -291,6 +300,40 @@ __global__ __launch_bounds__(256) void k_init_rays(PathState ps, float4* extO, f
         directionsOut[i] = make_float4(d.x, d.y, d.z, d.w);
     }
     path_start(ps, extO, extD, queue, i, ctx, o, d);
+}
+
+/* Cubemap_Bake's blend, cubemap.c:158: color[face][fi] = f3_lerpvs(color, result.color, weight); faces are contiguous here */
+__global__ __launch_bounds__(256) void k_cubemap_blend(const PimResult* __restrict__ results, float* __restrict__ faces, int32_t n, float weight)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* c = faces + (size_t)i * 3;
+    const PimResult r = results[i];
+    for (int k = 0; k < 3; ++k) c[k] = c[k] + (r.color[k] - c[k]) * weight;
+}
+
+/* AmbCube_Bake's fit loop, ambcube.c:22-30: a serial recurrence over the samples (order is part of the result),
+ * so ONE lane walks them; its wave stages 64 samples at a time through registers + shuffles */
+__global__ __launch_bounds__(64) void k_ambcube_fit(const PimResult* __restrict__ results, const float4* __restrict__ directions,
+    int32_t samples, float w, float4* __restrict__ cube)
+{
+    AmbCube c;
+    for (int k = 0; k < 6; ++k) { const float4 v = cube[k]; c.Values[k] = f4_v(v.x, v.y, v.z, v.w); }
+    for (int32_t base = 0; base < samples; base += 64)
+    {
+        const int32_t mine = base + (int32_t)threadIdx.x;
+        float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        if (mine < samples) { d = directions[mine]; const PimResult r = results[mine]; r0 = r.color[0]; r1 = r.color[1]; r2 = r.color[2]; }
+        const int32_t cnt = min(64, samples - base);
+        for (int32_t j = 0; j < cnt; ++j)
+        {
+            const v4 dir = f4_v(__shfl(d.x, j, 64), __shfl(d.y, j, 64), __shfl(d.z, j, 64), __shfl(d.w, j, 64));
+            const v4 rad = f4_v(__shfl(r0, j, 64), __shfl(r1, j, 64), __shfl(r2, j, 64), 0.0f);     /* f3_f4(result.color, 0), pt.c:2610 */
+            AmbCube_Fit(c, w, dir, rad);
+        }
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) cube[k] = make_float4(c.Values[k].x, c.Values[k].y, c.Values[k].z, c.Values[k].w);
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -925,7 +968,7 @@ static int trace_rays_common(PimScene* scene, const float* ro, const float* rd, 
         if (hipMalloc(&dirDev, sizeof(float4) * (size_t)n) != hipSuccess) { set_error("raygen: out of device memory"); return PIMGPU_E_NOMEM; }
         org = f4_v(origin[0], origin[1], origin[2], origin[3]);
     }
-    k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], roDev, rdDev, org, dirDev, n, sampleIndex, seed);
+    k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], roDev, rdDev, org, dirDev, n, sampleIndex, seed, 0);
     rc = integrate_paths(scene, n, maxBounces, nullptr, nullptr);
     if (!rc)
     {
@@ -960,6 +1003,66 @@ int pimgpu_raygen(PimScene* scene, const float* origin, int32_t count, uint32_t 
 {
     if (count > 0 && (!origin || !colors || !directions)) { set_error("raygen: NULL argument"); return PIMGPU_E_INVALID; }
     return trace_rays_common(scene, nullptr, nullptr, origin, count, sampleIndex, seed, maxBounces, nullptr, colors, directions);
+}
+
+int pimgpu_cubemap_bake(PimScene* scene, float* const faces[6], int32_t size, const float* origin, float weight,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !faces || !origin || size < 0 || size > 8192 || !(weight > 0.0f)) { set_error("cubemap_bake: bad argument"); return PIMGPU_E_INVALID; }
+    if (size == 0) return PIMGPU_OK;                          /* cubemap.c:172 */
+    for (int f = 0; f < 6; ++f) if (!faces[f]) { set_error("cubemap_bake: NULL face"); return PIMGPU_E_INVALID; }
+    if (size < 2) { set_error("cubemap_bake: size 1 divides by zero in LinearInvert (sampler.h:194)"); return PIMGPU_E_INVALID; }
+    const int32_t flen = size * size, n = flen * 6;
+    hipStream_t st = g_lib.stream;
+    WorkBuffers& w = g_lib.work;
+    if ((rc = w.ensure_paths(n))) return rc;
+    float* facesDev = nullptr;
+    if (hipMalloc(&facesDev, sizeof(float) * 3 * (size_t)n) != hipSuccess) { set_error("cubemap_bake: out of device memory"); return PIMGPU_E_NOMEM; }
+    for (int f = 0; f < 6; ++f) hipMemcpyAsync(facesDev + (size_t)f * flen * 3, faces[f], sizeof(float) * 3 * (size_t)flen, hipMemcpyHostToDevice, st);
+    k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], nullptr, nullptr,
+        f4_v(origin[0], origin[1], origin[2], origin[3]), nullptr, n, sampleIndex, seed, size);
+    rc = integrate_paths(scene, n, maxBounces, nullptr, nullptr);
+    if (!rc)
+    {
+        k_cubemap_blend<<<(n + 255) / 256, 256, 0, st>>>(w.results, facesDev, n, weight);
+        for (int f = 0; f < 6; ++f) hipMemcpyAsync(faces[f], facesDev + (size_t)f * flen * 3, sizeof(float) * 3 * (size_t)flen, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("cubemap_bake: device error"); rc = PIMGPU_E_DEVICE; }
+    }
+    hipFree(facesDev);
+    return rc;
+}
+
+int pimgpu_ambcube_bake(PimScene* scene, float* cube, const float* origin, int32_t samples, int32_t prevSampleCount,
+    uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, int32_t* newSampleCount)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !cube || !origin || samples < 0 || prevSampleCount < 0) { set_error("ambcube_bake: bad argument"); return PIMGPU_E_INVALID; }
+    hipStream_t st = g_lib.stream;
+    WorkBuffers& w = g_lib.work;
+    if (samples > 0)
+    {
+        if ((rc = w.ensure_paths(samples))) return rc;
+        float4* dirDev = nullptr; float4* cubeDev = nullptr;
+        if (hipMalloc(&dirDev, sizeof(float4) * (size_t)samples) != hipSuccess || hipMalloc(&cubeDev, sizeof(float4) * 6) != hipSuccess)
+        { hipFree(dirDev); set_error("ambcube_bake: out of device memory"); return PIMGPU_E_NOMEM; }
+        hipMemcpyAsync(cubeDev, cube, sizeof(float4) * 6, hipMemcpyHostToDevice, st);
+        k_init_rays<<<(samples + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], nullptr, nullptr,
+            f4_v(origin[0], origin[1], origin[2], origin[3]), dirDev, samples, sampleIndex, seed, 0);
+        rc = integrate_paths(scene, samples, maxBounces, nullptr, nullptr);
+        if (!rc)
+        {
+            float wgt = 6.0f / (1.0f + samples);                 /* ambcube.c:24-25 */
+            wgt = wgt / (1.0f + prevSampleCount);
+            k_ambcube_fit<<<1, 64, 0, st>>>(w.results, dirDev, samples, wgt, cubeDev);
+            hipMemcpyAsync(cube, cubeDev, sizeof(float4) * 6, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { set_error("ambcube_bake: device error"); rc = PIMGPU_E_DEVICE; }
+        }
+        hipFree(dirDev); hipFree(cubeDev);
+        if (rc) return rc;
+    }
+    if (newSampleCount) *newSampleCount = prevSampleCount + 1;
+    return PIMGPU_OK;
 }
 
 } /* extern "C" */

@@ -23,6 +23,7 @@ namespace pt {
 #define PT_TAG_BAKE_PT  0xA511E9B3u
 #define PT_TAG_EMIT     0x454D4954u
 #define PT_TAG_GRID     0x47524944u
+#define PT_TAG_CUBE     0x43554245u
 
 struct DTexture { int32_t width, height, format, _pad; const uint32_t* texels; };
 

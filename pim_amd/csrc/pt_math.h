@@ -750,6 +750,45 @@ PT_FN int Cubemap_CalcUv(v4 dir, v2* uvOut)
     return face;
 }
 
+/* f2_tent, math/float2_funcs.h:630-636.  As written in the reference: the y lane's upper branch reads
+ * Xi.x AFTER it was mapped (2 - Xi.x, not 2 - Xi.y); kept, the reference's golden vectors pin it. */
+PT_FN v2 f2_tent(v2 Xi)
+{
+    Xi = f2_v(Xi.x * 2.0f, Xi.y * 2.0f);
+    Xi.x = Xi.x < 1.0f ? pt_sqrt(Xi.x) - 1.0f : 1.0f - pt_sqrt(2.0f - Xi.x);
+    Xi.y = Xi.y < 1.0f ? pt_sqrt(Xi.y) - 1.0f : 1.0f - pt_sqrt(2.0f - Xi.x);
+    return Xi;
+}
+
+/* Cubemap_CalcDir, rendering/cubemap.h:190-207 (BilinearInvert / LinearInvert rendering/sampler.h:192-236,
+ * f2_snorm math/float2_funcs.h:620, Cubemap_kForwards / kRights / kUps rendering/cubemap.c:14-42) */
+PT_FN v4 Cubemap_CalcDir(int32_t size, int face, int32_t cx, int32_t cy, v2 Xi)
+{
+    v2 uv = f2_v((float)cx / (float)(size - 1), (float)cy / (float)(size - 1));
+    const float rcp = 1.0f / size;
+    Xi = f2_v(Xi.x * rcp, Xi.y * rcp);
+    uv = f2_v(uv.x + Xi.x, uv.y + Xi.y);
+    uv = f2_v(uv.x * 2.0f - 1.0f, uv.y * 2.0f - 1.0f);
+    const v4 fwd = f4_v(face == 0 ? 1.0f : (face == 1 ? -1.0f : 0.0f), face == 2 ? 1.0f : (face == 3 ? -1.0f : 0.0f),
+        face == 4 ? 1.0f : (face == 5 ? -1.0f : 0.0f), 0.0f);
+    const v4 right = f4_v((face == 2 || face == 4) ? 1.0f : ((face == 3 || face == 5) ? -1.0f : 0.0f), 0.0f,
+        (face == 0) ? -1.0f : ((face == 1) ? 1.0f : 0.0f), 0.0f);
+    const v4 up = f4_v(0.0f, (face == 2 || face == 3) ? 0.0f : 1.0f, (face == 2 || face == 3) ? -1.0f : 0.0f, 0.0f);
+    return proj_dir(right, up, fwd, f2_v(1.0f, 1.0f), uv);
+}
+
+/* AmbCube_Fit, math/ambcube.h:45-67 (AmbCube_t math/types.h:513-517) */
+struct AmbCube { v4 Values[6]; };
+PT_FN void AmbCube_Fit(AmbCube& c, float weight, v4 dir, v4 rad)
+{
+    const bool fx = dir.x > 0.0f, fy = dir.y > 0.0f, fz = dir.z > 0.0f;
+    dir = f4_mul(dir, dir);
+    dir = f4_muls(dir, weight);
+    if (fx) c.Values[0] = f4_lerps(c.Values[0], rad, dir.x); else c.Values[1] = f4_lerps(c.Values[1], rad, dir.x);
+    if (fy) c.Values[2] = f4_lerps(c.Values[2], rad, dir.y); else c.Values[3] = f4_lerps(c.Values[3], rad, dir.y);
+    if (fz) c.Values[4] = f4_lerps(c.Values[4], rad, dir.z); else c.Values[5] = f4_lerps(c.Values[5], rad, dir.z);
+}
+
 /* ---- geometry helpers: math/area.h:28, math/sdf.h:158-189 ---- */
 PT_FN float TriArea3D(v4 A, v4 B, v4 C) { return 0.5f * f4_length3(f4_cross3(f4_sub(B, A), f4_sub(C, A))); }
 PT_FN float sdTriangle3D(v4 a, v4 b, v4 c, v4 p)

@@ -127,6 +127,22 @@ void PtResults_Del(PtResults* results)
     results->colors = NULL; results->directions = NULL;
 }
 
+void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+{
+    if (!cm || !scene || cm->size <= 0) return;                      /* cubemap.c:168-173 */
+    float* faces[6];
+    for (int f = 0; f < 6; ++f) faces[f] = &cm->color[f]->x;
+    ok(pimgpu_cubemap_bake(scene, faces, cm->size, &origin.x, weight, sampleIndex, seed, maxBounces), "Cubemap_Bake");
+}
+
+i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+{
+    i32 count = prevSampleCount;
+    if (!scene || !pCube) return count;
+    ok(pimgpu_ambcube_bake(scene, &pCube->Values[0].x, &origin.x, samples, prevSampleCount, sampleIndex, seed, maxBounces, &count), "AmbCube_Bake");
+    return count;
+}
+
 void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces)
 {
     if (!scene || !pack || pack->lmCount <= 0) return;

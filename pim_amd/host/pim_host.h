@@ -60,6 +60,9 @@ typedef struct PtTrace
 
 /* Lightmap / LmPack, rendering/lightmap.h:27-44 (the fields BakeFn touches) */
 typedef struct Lightmap { float4* probes[5]; float3* position; float3* normal; float* sampleCounts; i32 size; } Lightmap;
+/* Cubemap (rendering/cubemap.h:28-34; the convolved mips are not on this path) and AmbCube_t (math/types.h:513-517) */
+typedef struct Cubemap { i32 size; float3* color[6]; } Cubemap;
+typedef struct AmbCube_t { float4 Values[6]; } AmbCube_t;
 typedef struct LmPack { Lightmap* lightmaps; i32 lmCount; i32 lmSize; float texelsPerMeter; } LmPack;
 
 bool PtSys_Init(void);                                   /* path_tracer.c:421-434 */
@@ -79,6 +82,10 @@ PtResult Pt_TraceRay(PtScene* scene, float4 ro, float4 rd, uint32_t sampleIndex,
 void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* camera);       /* :2557-2585 */
 PtResults Pt_RayGen(PtScene* scene, float4 origin, i32 count, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);   /* :2614-2644 */
 void PtResults_Del(PtResults* results);
+/* Cubemap_Bake, rendering/cubemap.h:209-213 / cubemap.c:162-190; AmbCube_Bake, math/ambcube.h:69-74 / ambcube.c:5-32.
+ * sampleIndex / seed / maxBounces: the per-work-item streams and the optional bounce clamp */
+void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
+i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
 
 /* rendering/lightmap.c:1204-1223; pages must be the reference's single allocation per lightmap (probes[0] = base) */
 void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces);

@@ -72,5 +72,26 @@ def test_pim_named_entry_points_match_oracle():
     r = host.Pt_TraceRay(scene, ro, rd, 2, 5, 4)
     r_o = o.trace_rays(np.array([[0.5, -1.0, 0.25, 0.0]], np.float32), np.array([[0.0, 0.6, 0.8, 0.0]], np.float32), 2, 5, 4)[0]
     assert tuple(np.float32(v) for v in r.color) == tuple(r_o["color"])
+
+    # Cubemap_Bake / AmbCube_Bake under their own names (rendering/cubemap.h:209, math/ambcube.h:69)
+    class Cubemap(C.Structure):
+        _fields_ = [("size", C.c_int32), ("color", C.c_void_p * 6)]
+    size = 8
+    fg = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
+    fo = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
+    cm = Cubemap(); cm.size = size
+    for f in range(6):
+        cm.color[f] = fg[f].ctypes.data
+    origin = Float4(0.25, -0.5, 0.5, 0.0)
+    host.Cubemap_Bake.argtypes = [C.c_void_p, C.c_void_p, Float4, C.c_float, C.c_uint32, C.c_uint32, C.c_int32]
+    host.Cubemap_Bake(C.byref(cm), scene, origin, 1.0, 0, 3, 4)
+    o.cubemap_bake(fo, size, np.array([0.25, -0.5, 0.5, 0.0], np.float32), 1.0, sampleIndex=0, seed=3, maxBounces=4)
+    assert all((a.view(np.uint32) == b.view(np.uint32)).all() for a, b in zip(fg, fo))
+    cube_g = np.zeros((6, 4), np.float32); cube_o = np.zeros((6, 4), np.float32)
+    host.AmbCube_Bake.restype = C.c_int32
+    host.AmbCube_Bake.argtypes = [C.c_void_p, C.c_void_p, Float4, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32]
+    n = host.AmbCube_Bake(scene, cube_g.ctypes.data_as(C.c_void_p), origin, 200, 0, 1, 3, 4)
+    assert n == 1 == o.ambcube_bake(cube_o, np.array([0.25, -0.5, 0.5, 0.0], np.float32), 200, 0, sampleIndex=1, seed=3, maxBounces=4)
+    assert (cube_g.view(np.uint32) == cube_o.view(np.uint32)).all()
     host.PtTrace_Del(C.byref(trace))
     host.PtScene_Del(scene)

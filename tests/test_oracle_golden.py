@@ -52,7 +52,8 @@ def test_golden_file_covers_the_survey_list():
                  "Fd_Burley", "F_0_F_90", "AlbedoToTransmittance", "reflect3", "refract3",
                  "GammaDecode_rgba8", "GammaEncode_rgba8", "UnpackEmission", "Bilinear", "Xy16ToNormalTs",
                  "Cubemap_CalcUv", "Grid", "Dist1D_Bake_Sample", "Dist1D_Update", "SG_Accumulate6",
-                 "GradientNoise3", "FbmGradientNoise3", "MiePhase", "camera_basis", "trs_flatten"]:
+                 "GradientNoise3", "FbmGradientNoise3", "MiePhase", "camera_basis", "trs_flatten",
+                 "f2_tent", "Cubemap_CalcDir", "AmbCube_Fit"]:
         assert need in names, need
 
 

@@ -111,3 +111,22 @@ def test_stddev_is_the_reference_formula(cornell):
     m, s = o.stddev(c, 40, 30)
     lum = c.astype(np.float64).sum(1) / 3
     assert abs(m - lum.mean()) < 1e-4 and abs(s - lum.std(ddof=1)) < 1e-4
+
+
+def test_cubemap_and_ambcube_bake_on_the_oracle(cornell):
+    """Cubemap_Bake / AmbCube_Bake restatements: deterministic, progressive, and the ambient cube of the closed
+    Cornell box is positive on all six axes"""
+    o = OracleScene(cornell.desc, accel=1)
+    size = 8
+    a = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
+    b = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
+    origin = np.array([0.0, 0.0, 0.5, 0.0], np.float32)
+    o.cubemap_bake(a, size, origin, 1.0, sampleIndex=0, seed=2, maxBounces=3)
+    o.cubemap_bake(b, size, origin, 1.0, sampleIndex=0, seed=2, maxBounces=3)
+    assert all((bits(x) == bits(y)).all() for x, y in zip(a, b)) and np.concatenate(a).mean() > 0
+    first = [x.copy() for x in a]
+    o.cubemap_bake(a, size, origin, 0.5, sampleIndex=1, seed=2, maxBounces=3)
+    assert any((x != y).any() for x, y in zip(a, first))
+    cube = np.zeros((6, 4), np.float32)
+    n = o.ambcube_bake(cube, origin, 256, 0, sampleIndex=0, seed=2, maxBounces=3)
+    assert n == 1 and (cube[:, :3] > 0).all()

@@ -120,6 +120,20 @@ class OracleScene:
                             C.c_int32(maxBounces), _p(colors), _p(directions), C.c_int(self.threads))
         return colors, directions
 
+    def cubemap_bake(self, faces, size, origin, weight, sampleIndex=0, seed=0, maxBounces=0):
+        arr = (C.c_void_p * 6)()
+        for f in range(6):
+            arr[f] = faces[f].ctypes.data
+        origin = api.f32(origin)
+        self.lib.orc_cubemap_bake(self.handle, arr, C.c_int32(size), _p(origin), C.c_float(weight), C.c_uint32(sampleIndex),
+                                  C.c_uint32(seed), C.c_int32(maxBounces), C.c_int(self.threads))
+
+    def ambcube_bake(self, cube, origin, samples, prevSampleCount=0, sampleIndex=0, seed=0, maxBounces=0):
+        origin = api.f32(origin)
+        self.lib.orc_ambcube_bake.restype = C.c_int32
+        return self.lib.orc_ambcube_bake(self.handle, _p(cube), _p(origin), C.c_int32(samples), C.c_int32(prevSampleCount),
+                                         C.c_uint32(sampleIndex), C.c_uint32(seed), C.c_int32(maxBounces), C.c_int(self.threads))
+
     def trace_image(self, images, width, height, camera, dof, params):
         """images = (color, albedo, normal) float32 (n,3) arrays updated in place (running mean); returns stats"""
         stats = api.PimTraceStats()
