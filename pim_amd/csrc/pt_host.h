@@ -33,7 +33,7 @@ int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why);
 /* per-process traversal resources: overflow area of the per-lane traversal stacks */
 struct TraceResources
 {
-    uint2* spill = nullptr;
+    unsigned long long* spill = nullptr;
     uint32_t* status = nullptr;          /* device word: bit 0 = traversal stack overflow */
     unsigned long long* work = nullptr;  /* device: nodes fetched, triangles tested, rays (counting build of the kernel) */
     bool counting = false;               /* pimgpu_work_counters(1, ..): launch the counting build */

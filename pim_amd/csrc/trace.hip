@@ -34,9 +34,9 @@ static constexpr int kTraceBlocksPerCU = 8;
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
-    uint2* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work)
+    unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work)
 {
-    __shared__ uint2 sStack[PT_STACK_LDS * kTraceThreads];
+    __shared__ unsigned long long sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
     LdsStack st;
     st.lds = sStack + threadIdx.x; st.ldsStride = kTraceThreads;
@@ -110,27 +110,36 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 const float4 ch = q[6];
                 float d[4]; int32_t c[4];
                 c[0] = __float_as_int(ch.x); c[1] = __float_as_int(ch.y); c[2] = __float_as_int(ch.z); c[3] = __float_as_int(ch.w);
-                const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
-                const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+                /* slab distances of the 4 boxes, two boxes per packed instruction (same IEEE operations per element) */
+                const f2 oxp = { pad.xp, pad.xp }, oyp = { pad.yp, pad.yp }, ozp = { pad.zp, pad.zp };
+                const f2 oxm = { pad.xm, pad.xm }, oym = { pad.ym, pad.ym }, ozm = { pad.zm, pad.zm };
+                const f2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz };
+                f2 ax[2], bx[2], ay[2], by[2], az[2], bz[2];
+                ax[0] = ((f2){ lox.x, lox.y } - oxp) * vix; ax[1] = ((f2){ lox.z, lox.w } - oxp) * vix;
+                bx[0] = ((f2){ hix.x, hix.y } - oxm) * vix; bx[1] = ((f2){ hix.z, hix.w } - oxm) * vix;
+                ay[0] = ((f2){ loy.x, loy.y } - oyp) * viy; ay[1] = ((f2){ loy.z, loy.w } - oyp) * viy;
+                by[0] = ((f2){ hiy.x, hiy.y } - oym) * viy; by[1] = ((f2){ hiy.z, hiy.w } - oym) * viy;
+                az[0] = ((f2){ loz.x, loz.y } - ozp) * viz; az[1] = ((f2){ loz.z, loz.w } - ozp) * viz;
+                bz[0] = ((f2){ hiz.x, hiz.y } - ozm) * viz; bz[1] = ((f2){ hiz.z, hiz.w } - ozm) * viz;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
-                    const float ax = (lx[k] - pad.xp) * ix, bx = (hx[k] - pad.xm) * ix;
-                    const float ay = (ly[k] - pad.yp) * iy, by = (hy[k] - pad.ym) * iy;
-                    const float az = (lz[k] - pad.zp) * iz, bz = (hz[k] - pad.zm) * iz;
-                    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
-                    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
+                    const float axk = ax[k >> 1][k & 1], bxk = bx[k >> 1][k & 1];
+                    const float ayk = ay[k >> 1][k & 1], byk = by[k >> 1][k & 1];
+                    const float azk = az[k >> 1][k & 1], bzk = bz[k >> 1][k & 1];
+                    float t0 = fmaxf(fmaxf(fminf(axk, bxk), fminf(ayk, byk)), fmaxf(fminf(azk, bzk), tNear));
+                    float t1 = fminf(fminf(fmaxf(axk, bxk), fmaxf(ayk, byk)), fmaxf(azk, bzk)) * 1.0000004f;   /* conservative slab (Ize 2013) */
                     t1 = fminf(t1, h.t);
+                    /* empty slots carry an inverted box, which the min/max slab test would read as infinite: test the tag */
                     d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
                 }
+                /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
                 PT_SWAP_IF(d[0], c[0], d[1], c[1]);
                 PT_SWAP_IF(d[2], c[2], d[3], c[3]);
                 PT_SWAP_IF(d[0], c[0], d[2], c[2]);
                 PT_SWAP_IF(d[1], c[1], d[3], c[3]);
                 PT_SWAP_IF(d[1], c[1], d[2], c[2]);
-                if (d[3] < __builtin_inff()) overflow |= !st.push(d[3], c[3]);
-                if (d[2] < __builtin_inff()) overflow |= !st.push(d[2], c[2]);
-                if (d[1] < __builtin_inff()) overflow |= !st.push(d[1], c[1]);
+                overflow |= !st.push3(d[1], c[1], d[2], c[2], d[3], c[3]);
                 cur = (d[0] < __builtin_inff()) ? c[0] : PT_BVH_EMPTY;
             }
             /* B: one triangle of the current leaf */
@@ -198,7 +207,7 @@ int TraceResources::ensure()
     if (const char* e = getenv("PIMGPU_TRACE_BLOCKS_PER_CU")) perCU = std::max(1, std::min(16, atoi(e)));      /* tuning knob */
     gridBlocks = prop.multiProcessorCount * perCU;
     const size_t lanes = (size_t)gridBlocks * kTraceThreads;
-    PT_HIP(hipMalloc(&spill, sizeof(uint2) * lanes * PT_STACK_SPILL));
+    PT_HIP(hipMalloc(&spill, sizeof(unsigned long long) * lanes * PT_STACK_SPILL));
     PT_HIP(hipMalloc(&status, 256));
     PT_HIP(hipMemset(status, 0, 256));
     work = (unsigned long long*)(status + 32);       /* bytes 128..: nodes, tris, rays of the counting build */

@@ -27,9 +27,11 @@
 
 namespace pt {
 
-#define PT_STACK_LDS    8
-#define PT_STACK_SPILL  56
+#define PT_STACK_LDS    12
+#define PT_STACK_SPILL  52
 #define PT_STACK_MAX    (PT_STACK_LDS + PT_STACK_SPILL)
+
+typedef float f2 __attribute__((ext_vector_type(2)));      /* packed fp32 math: v_pk_add_f32 / v_pk_mul_f32 */
 
 struct RayPre
 {
@@ -137,20 +139,21 @@ struct TrivialStack
     }
 };
 
+/* entries are one 64-bit word: child in the high half, entry distance (float bits) in the low half */
 struct LdsStack
 {
-    uint2* lds;         /* &shared[threadIdx.x], stride ldsStride */
-    uint2* spill;       /* &spill[global lane slot], stride spillStride */
+    unsigned long long* lds;    /* &shared[threadIdx.x], stride ldsStride */
+    unsigned long long* spill;  /* &spill[global lane slot], stride spillStride */
     int ldsStride;
     int64_t spillStride;
     int sp;
+    __device__ __forceinline__ static unsigned long long pack(float t, int32_t c) { return ((unsigned long long)(uint32_t)c << 32) | (unsigned long long)__float_as_uint(t); }
     __device__ __forceinline__ void init() { sp = 0; }
     __device__ __forceinline__ bool push(float t, int32_t c)
     {
         if (sp >= PT_STACK_MAX) return false;
-        const uint2 v = make_uint2(__float_as_uint(t), (uint32_t)c);
-        if (sp < PT_STACK_LDS) lds[sp * ldsStride] = v;
-        else spill[(int64_t)(sp - PT_STACK_LDS) * spillStride] = v;
+        if (sp < PT_STACK_LDS) lds[sp * ldsStride] = pack(t, c);
+        else spill[(int64_t)(sp - PT_STACK_LDS) * spillStride] = pack(t, c);
         ++sp;
         return true;
     }
@@ -158,9 +161,31 @@ struct LdsStack
     {
         if (sp == 0) return false;
         --sp;
-        const uint2 v = (sp < PT_STACK_LDS) ? lds[sp * ldsStride] : spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
-        *t = __uint_as_float(v.x); *c = (int32_t)v.y;
+        unsigned long long v;
+        if (sp < PT_STACK_LDS) v = lds[sp * ldsStride];                        /* two typed loads: no generic-address access */
+        else v = spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
+        *t = __uint_as_float((uint32_t)v); *c = (int32_t)(v >> 32);
         return true;
+    }
+    /* up to three entries, farthest first, d1 <= d2 <= d3 with misses (+inf) last; the common case (all of them fit
+     * the LDS part) is three predicated 64-bit LDS stores without a branch per entry */
+    __device__ __forceinline__ bool push3(float d1, int32_t c1, float d2, int32_t c2, float d3, int32_t c3)
+    {
+        const float inf = __builtin_inff();
+        const int n = (d1 < inf ? 1 : 0) + (d2 < inf ? 1 : 0) + (d3 < inf ? 1 : 0);
+        if (sp + n <= PT_STACK_LDS)
+        {
+            if (n >= 3) lds[sp * ldsStride] = pack(d3, c3);
+            if (n >= 2) lds[(sp + n - 2) * ldsStride] = pack(d2, c2);
+            if (n >= 1) lds[(sp + n - 1) * ldsStride] = pack(d1, c1);
+            sp += n;
+            return true;
+        }
+        bool ok = true;
+        if (d3 < inf) ok &= push(d3, c3);
+        if (d2 < inf) ok &= push(d2, c2);
+        if (d1 < inf) ok &= push(d1, c1);
+        return ok;
     }
 };
 
