@@ -213,6 +213,42 @@ void* pimgpu_stream(void);
  * the counters are then cleared.  These are the per-ray figures of the roofline's algorithmic bytes. */
 int pimgpu_work_counters(int enable, uint64_t* out);
 
+/* ---- scene inputs --------------------------------------------------------- */
+
+/* Mesh, rendering/mesh.h:25-33: the three arrays FlattenDrawables reads, float4[length] each, host */
+typedef struct PimMesh
+{
+    int32_t      length;
+    int32_t      _pad;
+    const float* positions;
+    const float* normals;
+    const float* uvs;
+} PimMesh;
+
+/* the columns of the Entities table FlattenDrawables reads (rendering/drawable.h:14-27) and the
+ * mesh table behind Mesh_Get (rendering/mesh.h:55) */
+typedef struct PimDrawables
+{
+    int32_t            count;
+    int32_t            meshCount;
+    const int32_t*     meshes;     /* [count] index into meshTable; < 0 = Mesh_Get() returns NULL, entity skipped */
+    const float*       matrices;   /* float4x4[count], columns c0 c1 c2 c3 (math/types.h:392-398) */
+    const PimMaterial* materials;  /* [count] */
+    const PimMesh*     meshTable;  /* [meshCount] */
+} PimDrawables;
+
+/* FlattenDrawables (rendering/path_tracer.c:692-782).  flatten_counts is its sizing pass (:701-712);
+ * flatten fills caller-owned host arrays of those sizes: float4 positions/normals[vertCount],
+ * float2 uvs[vertCount], i32 matIds[vertCount], materials[matCount] -- the first five fields of PimSceneDesc. */
+int pimgpu_flatten_counts(const PimDrawables* drawables, int32_t* vertCount, int32_t* matCount);
+int pimgpu_flatten(const PimDrawables* drawables, float* positions, float* normals, float* uvs,
+    int32_t* matIds, PimMaterial* materials);
+
+/* BakeBrdfFn (math/lighting.c:31-84) as driven by BrdfLut_New (:86-99, prevSamples = 0 on a zeroed table)
+ * and BrdfLut_Update (:107-118): adds samples [prevSamples, numSamples) to every texel of the host table
+ * float2[width*height] (g_BrdfLut, lighting.h:45-55).  Texel i draws from the stream Pcg4(i, prevSamples, seed, k). */
+int pimgpu_brdf_lut_bake(float* texels, int32_t width, int32_t height, int32_t prevSamples, int32_t numSamples, uint32_t seed);
+
 /* ---- scene --------------------------------------------------------------- */
 
 /* PtScene_New -> PtScene_Init (path_tracer.c:1039-1049,1083-1093):

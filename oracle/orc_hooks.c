@@ -84,6 +84,12 @@ HOOK(UvBilinearClamp_4x4)
 }
 HOOK(Cubemap_CalcUv) { v2 uv; int f = Cubemap_CalcUv(F3(in, 0, 0.0f), &uv); out[0] = (uint32_t)f; PF(out, 1, uv.x); PF(out, 2, uv.y); }
 
+HOOK(brdf_lut_sample)
+{
+    const float rcp = 1.0f / (float)(int32_t)in[2], dx = 1.0f / (float)(int32_t)in[3];
+    v2 r = BrdfLutSample((int32_t)in[0], (int32_t)in[1], rcp, rcp, dx, o2(F(in, 4), F(in, 5)), F(in, 6), o2(F(in, 7), F(in, 8)));
+    PF(out, 0, r.x); PF(out, 1, r.y);
+}
 HOOK(f2_tent) { v2 r = f2_tent(o2(F(in, 0), F(in, 1))); PF(out, 0, r.x); PF(out, 1, r.y); }
 HOOK(Cubemap_CalcDir) { v4 d = Cubemap_CalcDir((int32_t)in[0], (int)in[1], (int32_t)in[2], (int32_t)in[3], o2(F(in, 4), F(in, 5))); PF(out, 0, d.x); PF(out, 1, d.y); PF(out, 2, d.z); }
 HOOK(AmbCube_Fit)

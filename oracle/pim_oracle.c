@@ -1813,6 +1813,73 @@ void orc_flatten_entity(const float* translation, const float* rotation, const f
     }
 }
 
+/* FlattenDrawables, pt.c:692-782 */
+void orc_flatten(const PimDrawables* d, float* positions, float* normals, float* uvs, int32_t* matIds, PimMaterial* materials)
+{
+    int32_t vertCount = 0, matCount = 0;
+    for (int32_t i = 0; i < d->count; ++i)
+    {
+        if (d->meshes[i] < 0) continue;                                 /* Mesh_Get() == NULL, :726-729 */
+        const PimMesh* mesh = &d->meshTable[d->meshes[i]];
+        const int32_t meshLen = mesh->length;
+        const int32_t vertBack = vertCount, matBack = matCount;
+        vertCount += meshLen; matCount += 1;
+        const float* c = d->matrices + (size_t)i * 16;
+        m44 M;
+        M.c0 = o4(c[0], c[1], c[2], c[3]); M.c1 = o4(c[4], c[5], c[6], c[7]);
+        M.c2 = o4(c[8], c[9], c[10], c[11]); M.c3 = o4(c[12], c[13], c[14], c[15]);
+        const m33 IM = m44_IM(M);
+        materials[matBack] = d->materials[i];
+        for (int32_t j = 0; j < meshLen; ++j)
+        {
+            const v4 p = m44_mul_pt(M, ld4(mesh->positions, j));
+            const v4 n = o4_normalize3(m33_mul_col(IM, ld4(mesh->normals, j)));
+            float* P = positions + (size_t)(vertBack + j) * 4; float* N = normals + (size_t)(vertBack + j) * 4;
+            P[0] = p.x; P[1] = p.y; P[2] = p.z; P[3] = p.w;
+            N[0] = n.x; N[1] = n.y; N[2] = n.z; N[3] = n.w;
+            uvs[(size_t)(vertBack + j) * 2 + 0] = 0.0f; uvs[(size_t)(vertBack + j) * 2 + 1] = 0.0f;    /* Perm_Calloc */
+            matIds[vertBack + j] = matBack;
+        }
+        for (int32_t j = 0; (j + 3) <= meshLen; j += 3)               /* whole triangles only, :755-766 */
+        {
+            for (int32_t k = 0; k < 3; ++k)
+            {
+                uvs[(size_t)(vertBack + j + k) * 2 + 0] = mesh->uvs[(size_t)(j + k) * 4 + 0];
+                uvs[(size_t)(vertBack + j + k) * 2 + 1] = mesh->uvs[(size_t)(j + k) * 4 + 1];
+            }
+        }
+    }
+}
+
+/* BakeBrdfFn, math/lighting.c:31-84; the texel's stream is build-defined, tag shared with prepare.hip */
+#define TAG_LUT 0x4C555421u
+void orc_brdf_lut_bake(float* texels, int32_t sx, int32_t sy, int32_t prevSamples, int32_t numSamples, uint32_t seed)
+{
+    if (numSamples <= prevSamples) return;                              /* BrdfLut_Update, :110 */
+    const int32_t deltaSamples = numSamples - prevSamples;
+    const float dx = 1.0f / (float)deltaSamples;
+    const float dt = (float)deltaSamples / (float)numSamples;
+    const float rcpWidth = 1.0f / (float)sx, rcpHeight = 1.0f / (float)sy;
+    for (int32_t iTexel = 0; iTexel < sx * sy; ++iTexel)
+    {
+        const int32_t cx = iTexel % sx, cy = iTexel / sx;
+        u4 rng = pcg4((uint32_t)iTexel, (uint32_t)prevSamples, seed, TAG_LUT);
+        v2 result = o2(0.0f, 0.0f);
+        for (int32_t iSample = prevSamples; iSample < numSamples; ++iSample)
+        {
+            const v2 XiAA = rng_f2(&rng);
+            const float XiPhi = rng_f32(&rng);
+            const v2 XiH = rng_f2(&rng);
+            const v2 c = BrdfLutSample(cx, cy, rcpWidth, rcpHeight, dx, XiAA, XiPhi, XiH);
+            result.x += c.x;
+            result.y += c.y;
+        }
+        v2 old = o2(texels[iTexel * 2 + 0], texels[iTexel * 2 + 1]);
+        v2 r = o2_lerps(old, result, dt);
+        texels[iTexel * 2 + 0] = r.x; texels[iTexel * 2 + 1] = r.y;
+    }
+}
+
 /* shims for oracle/orc_hooks.c (golden-vector pinning of the Dist1D restatement) */
 float orc_test_dist_bake(float* pdf, float* cdf, int32_t len) { return dist_bake(pdf, cdf, len); }
 int32_t orc_test_dist_find(const float* cdf, int32_t size, float u) { return dist_find_interval(cdf, size, u); }

@@ -346,6 +346,39 @@ int main(int argc, char** argv)
     }
     end("AmbCube_Fit", N, 32, 24);
 
+    /* ---- one sample of the BRDF table bake (math/lighting.c:53-80; BakeBrdfFn itself is a static function of a
+     * translation unit that needs the Vulkan headers, so the record evaluates the reference's own header functions
+     * in the order that loop calls them) ---- */
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        const i32 size = (i & 1) ? 128 : 32;
+        const i32 cx = (i32)(nextu() % (u32)size), cy = (i < 8) ? 0 : (i32)(nextu() % (u32)size);
+        const i32 spp = 1 + (i32)(nextu() % 16u);
+        const float2 XiAA = { rnd(), rnd() }, XiH = { rnd(), rnd() };
+        const float XiPhi = rnd();
+        const float rcp = 1.0f / size, wgt = 1.0f / spp;
+        const float2 jit = SampleGaussPixelFilter(XiAA, 0.5f);
+        const float cosV = f1_clamp((cx + jit.x) * rcp, kEpsilon, 1.0f - kEpsilon);
+        const float a = f1_clamp((cy + jit.y) * rcp, kMinAlpha, 1.0f);
+        const float4 view = SphericalToCartesian(cosV, XiPhi * kTau);
+        const float4 half = SampleGGXMicrofacet(XiH, a);
+        const float4 lightDir = f4_reflect3(f4_neg(view), half);
+        const float hv = f4_dot3(half, view);
+        const float p = GGXPdf(half.z, hv, a);
+        float outA = 0.0f, outB = 0.0f;
+        if ((lightDir.z > kEpsilon) && (p > kEpsilon))
+        {
+            const float term = (D_GTR(half.z, a) / p) * V_SmithCorrelated(lightDir.z, cosV, a) * lightDir.z * wgt;
+            outA = term * F_Dielectric(hv, 1.000293f, 1.52f);
+            outB = term;
+        }
+        putu((u32)cx); putu((u32)cy); putu((u32)size); putu((u32)spp);
+        putf(XiAA.x); putf(XiAA.y); putf(XiPhi); putf(XiH.x); putf(XiH.y);
+        putf(outA); putf(outB);
+    }
+    end("brdf_lut_sample", N, 9, 2);
+
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);
     fclose(s_out);

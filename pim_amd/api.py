@@ -76,6 +76,16 @@ class PimTraceStats(C.Structure):
                 ("paths", C.c_uint64), ("bounces", C.c_int32), ("traceMs", C.c_float), ("totalMs", C.c_float)]
 
 
+class PimMesh(C.Structure):
+    _fields_ = [("length", C.c_int32), ("_pad", C.c_int32), ("positions", C.c_void_p), ("normals", C.c_void_p),
+                ("uvs", C.c_void_p)]
+
+
+class PimDrawables(C.Structure):
+    _fields_ = [("count", C.c_int32), ("meshCount", C.c_int32), ("meshes", C.c_void_p), ("matrices", C.c_void_p),
+                ("materials", C.c_void_p), ("meshTable", C.c_void_p)]
+
+
 class PimLightmapPage(C.Structure):
     _fields_ = [("block", C.c_void_p)]
 
@@ -95,6 +105,7 @@ EXPORTS = [
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
+    "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
 ]
 
@@ -280,6 +291,57 @@ class Trace:
         out = PimTraceStats()
         check(self.lib.pimgpu_trace_stats(self.handle, C.byref(out)), "pimgpu_trace_stats")
         return out
+
+
+class Drawables:
+    """the Entities columns + mesh table FlattenDrawables reads (rendering/drawable.h:14-27, mesh.h:25-33), kept alive
+    as numpy arrays behind a PimDrawables struct.  meshes: list of (positions, normals, uvs) float32 (len,4) arrays;
+    mesh_ids: per entity index into meshes (-1 = no mesh); matrices: (count,4,4) float32 with matrices[i][c] = column c."""
+
+    def __init__(self, meshes, mesh_ids, matrices, materials):
+        self.keep = []
+        self.table = (PimMesh * max(1, len(meshes)))()
+        for i, (P, N, U) in enumerate(meshes):
+            P, N, U = f32(P), f32(N), f32(U)
+            assert P.shape == N.shape == U.shape and (P.ndim == 2 and P.shape[1] == 4 or P.size == 0)
+            self.keep += [P, N, U]
+            self.table[i].length = P.shape[0]
+            self.table[i].positions, self.table[i].normals, self.table[i].uvs = P.ctypes.data, N.ctypes.data, U.ctypes.data
+        self.mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
+        self.matrices = f32(matrices).reshape(-1, 16)
+        self.materials = (PimMaterial * max(1, len(materials)))(*materials)
+        assert self.matrices.shape[0] == self.mesh_ids.shape[0] == len(materials)
+        self.desc = PimDrawables()
+        self.desc.count = self.mesh_ids.shape[0]
+        self.desc.meshCount = len(meshes)
+        self.desc.meshes = self.mesh_ids.ctypes.data
+        self.desc.matrices = self.matrices.ctypes.data
+        self.desc.materials = C.cast(self.materials, C.c_void_p)
+        self.desc.meshTable = C.cast(self.table, C.c_void_p)
+
+
+def flatten_counts(drawables):
+    v, m = C.c_int32(), C.c_int32()
+    check(load_library().pimgpu_flatten_counts(C.byref(drawables.desc), C.byref(v), C.byref(m)), "pimgpu_flatten_counts")
+    return v.value, m.value
+
+
+def flatten(drawables):
+    """FlattenDrawables on the GPU -> positions (V,4), normals (V,4), uvs (V,2), matIds (V,), materials (ctypes array)"""
+    V, M = flatten_counts(drawables)
+    P, N = np.zeros((V, 4), np.float32), np.zeros((V, 4), np.float32)
+    U, ids = np.zeros((V, 2), np.float32), np.zeros(V, np.int32)
+    mats = (PimMaterial * max(1, M))()
+    check(load_library().pimgpu_flatten(C.byref(drawables.desc), _ptr(P), _ptr(N), _ptr(U), _ptr(ids), mats), "pimgpu_flatten")
+    return P, N, U, ids, mats
+
+
+def brdf_lut_bake(texels, prevSamples, numSamples, seed=0):
+    """BakeBrdfFn (math/lighting.c:31-84) over a float32 (height, width, 2) table, in place"""
+    assert texels.dtype == np.float32 and texels.flags["C_CONTIGUOUS"] and texels.ndim == 3 and texels.shape[2] == 2
+    check(load_library().pimgpu_brdf_lut_bake(_ptr(texels), C.c_int32(texels.shape[1]), C.c_int32(texels.shape[0]),
+          C.c_int32(prevSamples), C.c_int32(numSamples), C.c_uint32(seed)), "pimgpu_brdf_lut_bake")
+    return texels
 
 
 def work_counters(enable):

@@ -637,6 +637,32 @@ PT_FN float Fd_Burley(float NoL, float NoV, float HoV, float roughness)         
     return (lightScatter * viewScatter) / PT_PI;
 }
 
+/* one sample of BakeBrdfFn's loop body (math/lighting.c:53-80) for LUT texel (cx, cy): the sample's weighted
+ * contribution (D*G*NoL*dx*Fc, D*G*NoL*dx), zero when the reflected direction is below the horizon */
+PT_FN v2 BrdfLutSample(int32_t cx, int32_t cy, float rcpWidth, float rcpHeight, float dx, v2 XiAA, float XiPhi, v2 XiH)
+{
+    const v2 aa = SampleGaussPixelFilter(XiAA, 0.5f);
+    const float NoV = f1_clamp(((float)cx + aa.x) * rcpWidth, PT_EPS, 1.0f - PT_EPS);
+    const float alpha = f1_clamp(((float)cy + aa.y) * rcpHeight, PT_MIN_ALPHA, 1.0f);
+    const v4 V = SphericalToCartesian(NoV, XiPhi * PT_TAU);
+    const v4 H = SampleGGXMicrofacet(XiH, alpha);                      /* N = (0, 0, 1) */
+    const v4 L = f4_reflect3(f4_neg(V), H);
+    const float NoL = L.z, NoH = H.z;
+    const float HoV = f4_dot3(H, V);
+    const float pdf = GGXPdf(NoH, HoV, alpha);
+    v2 r = f2_v(0.0f, 0.0f);
+    if ((NoL > PT_EPS) && (pdf > PT_EPS))
+    {
+        const float D = D_GTR(NoH, alpha) / pdf;
+        const float G = V_SmithCorrelated(NoL, NoV, alpha);
+        const float Fc = F_Dielectric(HoV, 1.000293f, 1.52f);
+        const float DG_NoL_dx = D * G * NoL * dx;
+        r.x = DG_NoL_dx * Fc;
+        r.y = DG_NoL_dx;
+    }
+    return r;
+}
+
 /* ---- colour / texel decode: math/color.h ---- */
 PT_FN v4 rgba8_to_f4(uint32_t c)                                                                /* :113-117 (r = low byte) */
 {

@@ -36,6 +36,47 @@ PtScene* PtScene_New(const PimSceneDesc* snapshot)
     return scene;
 }
 
+PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneDesc* rest)
+{
+    if (!rest) { snprintf(ms_error, sizeof(ms_error), "PtScene_NewFromDrawables: NULL snapshot"); return NULL; }
+    int32_t vertCount = 0, matCount = 0;
+    if (!ok(pimgpu_flatten_counts(drawables, &vertCount, &matCount), "FlattenDrawables")) return NULL;
+    /* Perm_Calloc in the reference (path_tracer.c:715-721) */
+    float* positions = calloc((size_t)vertCount + 1, 4 * sizeof(float));
+    float* normals = calloc((size_t)vertCount + 1, 4 * sizeof(float));
+    float* uvs = calloc((size_t)vertCount + 1, 2 * sizeof(float));
+    int32_t* matIds = calloc((size_t)vertCount + 1, sizeof(int32_t));
+    PimMaterial* materials = calloc((size_t)matCount + 1, sizeof(PimMaterial));
+    PtScene* scene = NULL;
+    if (positions && normals && uvs && matIds && materials &&
+        ok(pimgpu_flatten(drawables, positions, normals, uvs, matIds, materials), "FlattenDrawables"))
+    {
+        PimSceneDesc desc = *rest;
+        desc.vertCount = vertCount; desc.matCount = matCount;
+        desc.positions = positions; desc.normals = normals; desc.uvs = uvs; desc.matIds = matIds; desc.materials = materials;
+        scene = PtScene_New(&desc);
+    }
+    free(positions); free(normals); free(uvs); free(matIds); free(materials);      /* the scene keeps its own copies in HBM */
+    return scene;
+}
+
+BrdfLut BrdfLut_New(int2 size, i32 numSamples, uint32_t seed)
+{
+    BrdfLut lut = { size, NULL };
+    if (size.x <= 0 || size.y <= 0) { lut.size.x = lut.size.y = 0; return lut; }
+    lut.texels = calloc((size_t)size.x * (size_t)size.y, sizeof(float2));           /* Tex_Calloc, lighting.c:92 */
+    if (lut.texels) BrdfLut_Update(&lut, 0, numSamples, seed);
+    return lut;
+}
+
+void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples, uint32_t seed)
+{
+    if (lut && lut->texels && (newSamples > prevSamples))                           /* lighting.c:110 */
+        ok(pimgpu_brdf_lut_bake(&lut->texels[0].x, lut->size.x, lut->size.y, prevSamples, newSamples, seed), "BrdfLut_Update");
+}
+
+void BrdfLut_Del(BrdfLut* lut) { if (lut) { free(lut->texels); memset(lut, 0, sizeof(*lut)); } }
+
 void PtScene_Update(PtScene* scene) { if (scene) ok(pimgpu_scene_update_dists(scene), "PtScene_Update"); }
 void PtScene_Del(PtScene* scene) { if (scene) pimgpu_scene_destroy(scene); }
 

@@ -70,8 +70,19 @@ void PtSys_Shutdown(void);                               /* :439-446 */
 const char* PtSys_LastError(void);
 
 PtScene* PtScene_New(const PimSceneDesc* snapshot);      /* :1083-1093 */
+/* FlattenDrawables (path_tracer.c:692-782) + PtScene_Init: the first five fields of `rest` (vertCount, matCount, positions,
+ * normals, uvs, matIds, materials) are ignored and filled from the GPU-flattened draw table */
+PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneDesc* rest);
 void PtScene_Update(PtScene* scene);                     /* :1023-1037 (UpdateDists; a changed scene is a new snapshot) */
 void PtScene_Del(PtScene* scene);                        /* :1095-1102 */
+
+/* BrdfLut, math/lighting.h:45-55; BrdfLut_New / BrdfLut_Update / BrdfLut_Del, math/lighting.c:86-118.  seed: the per-texel
+ * streams */
+typedef struct { float x, y; } float2;
+typedef struct BrdfLut { int2 size; float2* texels; } BrdfLut;
+BrdfLut BrdfLut_New(int2 size, i32 numSamples, uint32_t seed);
+void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples, uint32_t seed);
+void BrdfLut_Del(BrdfLut* lut);
 
 void PtTrace_New(PtTrace* trace, int2 imageSize);        /* :1117-1131 */
 void PtTrace_Del(PtTrace* trace);                        /* :1133-1139 */

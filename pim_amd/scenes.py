@@ -196,6 +196,7 @@ class SceneBuilder:
         self.media = default_media()
         self.lut = None
         self._flat = {}
+        self.entities = []          # (mesh, t, q, s, material index) of every add(): the draw table before flattening
 
     def flat_texture(self, value):
         key = tuple(np.asarray(value, F).tolist())
@@ -221,6 +222,7 @@ class SceneBuilder:
 
     def add(self, mesh, t, q, s, mat):
         P, N, U = flatten_entity(t, q, s, mesh)
+        self.entities.append((mesh, np.asarray(t, F), np.asarray(q, F), np.asarray(s, F), mat))
         self.pos.append(P); self.nor.append(N); self.uv.append(U)
         self.mat.append(np.full(P.shape[0], mat, np.int32))
 
@@ -247,6 +249,8 @@ class SceneData:
             self.textures[i].width, self.textures[i].height, self.textures[i].format = w, h, fmt
             self.textures[i].texels = texels.ctypes.data
         self.lut = b.lut if b.lut is not None else brdf_lut()
+        self.entities = b.entities
+        self.builder_materials = b.materials
         self.sky = sky_faces(b.sky_size) if b.sky_size > 0 else None
         d = api.PimSceneDesc()
         d.vertCount = self.positions.shape[0]
@@ -273,6 +277,29 @@ class SceneData:
     @property
     def tri_count(self):
         return self.positions.shape[0] // 3
+
+
+def drawables_of(sc):
+    """the draw table (Entities columns + mesh table, rendering/drawable.h:14-27) of a scene made with SceneBuilder.add only:
+    what FlattenDrawables reads.  Each entity carries its own copy of its material, as Entities.materials does."""
+    meshes, index, ids, mats = [], {}, [], []
+    M = np.zeros((len(sc.entities), 4, 4), F)
+    for i, (mesh, t, q, s, mat) in enumerate(sc.entities):
+        if id(mesh[0]) not in index:
+            pos, nor, uv = mesh
+            n = pos.shape[0]
+            P = np.zeros((n, 4), F); P[:, :3] = pos; P[:, 3] = 1.0
+            N = np.zeros((n, 4), F); N[:, :3] = nor
+            U = np.zeros((n, 4), F); U[:, :2] = uv
+            index[id(mesh[0])] = len(meshes)
+            meshes.append((P, N, U))
+        ids.append(index[id(mesh[0])])
+        c = trs_matrix(t, q, s)
+        for k in range(4):
+            M[i, k, :3] = c[k]
+        M[i, 3, 3] = 1.0
+        mats.append(sc.builder_materials[mat])
+    return api.Drawables(meshes, np.array(ids, np.int32), M, mats)
 
 
 def default_media():

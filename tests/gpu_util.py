@@ -15,6 +15,9 @@ def gpu_init():
 
 def assert_bits_equal(a, b, what):
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    assert a.shape == b.shape, f"{what}: shapes {a.shape} / {b.shape}"
+    if a.size == 0:
+        return
     av = a.view(np.uint32) if a.dtype == np.float32 else a
     bv = b.view(np.uint32) if b.dtype == np.float32 else b
     bad = np.nonzero((av != bv).reshape(av.shape[0], -1).any(axis=1))[0] if av.ndim > 1 else np.nonzero(av != bv)[0]

@@ -95,3 +95,41 @@ def test_pim_named_entry_points_match_oracle():
     assert (cube_g.view(np.uint32) == cube_o.view(np.uint32)).all()
     host.PtTrace_Del(C.byref(trace))
     host.PtScene_Del(scene)
+
+
+def test_scene_producers_under_pim_names():
+    """FlattenDrawables + PtScene_New (PtScene_NewFromDrawables) and BrdfLut_New / BrdfLut_Update (math/lighting.c:86-118)
+    through the plain-C host layer: same bits as the C-ABI calls they wrap"""
+    host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
+    host.PtSys_Init.restype = C.c_bool
+    assert host.PtSys_Init()
+
+    class BrdfLut(C.Structure):
+        _fields_ = [("size", Int2), ("texels", C.POINTER(C.c_float))]
+    host.BrdfLut_New.restype = BrdfLut
+    host.BrdfLut_New.argtypes = [Int2, C.c_int32, C.c_uint32]
+    lut = host.BrdfLut_New(Int2(32, 32), 48, 7)
+    assert lut.texels and lut.size.x == 32
+    host.BrdfLut_Update(C.byref(lut), 48, 64, C.c_uint32(7))
+    table = np.ctypeslib.as_array(lut.texels, shape=(32, 32, 2)).copy()
+    want = np.zeros((32, 32, 2), np.float32)
+    api.brdf_lut_bake(want, 0, 48, seed=7); api.brdf_lut_bake(want, 48, 64, seed=7)
+    assert (table.view(np.uint32) == want.view(np.uint32)).all() and table.max() > 0.5
+
+    sc = scenes.cornell_box()
+    dr = scenes.drawables_of(sc)
+    rest = api.PimSceneDesc.from_buffer_copy(bytes(sc.desc))
+    rest.brdfLut, rest.brdfLutSize = C.cast(lut.texels, C.c_void_p), 32
+    host.PtScene_NewFromDrawables.restype = C.c_void_p
+    scene = C.c_void_p(host.PtScene_NewFromDrawables(C.byref(dr.desc), C.byref(rest)))
+    assert scene
+    info = api.PimSceneInfo()
+    assert api.load_library().pimgpu_scene_info(scene, C.byref(info)) == 0
+    assert info.triCount == 108 and info.matCount == 9 and info.emissiveCount == 12
+    host.Pt_Intersect.restype = PtRayHit
+    host.Pt_Intersect.argtypes = [C.c_void_p, Float4, Float4, C.c_float, C.c_float]
+    h = host.Pt_Intersect(scene, Float4(0.5, -1.0, 0.25, 0.0), Float4(0.0, 0.6, 0.8, 0.0), 0.0, api.RCP_EPSILON)
+    assert h.type == api.HIT_TRIANGLE and h.wuvt.w > 0.0
+    host.PtScene_Del(scene)
+    host.BrdfLut_Del(C.byref(lut))
+    assert not lut.texels

@@ -1,0 +1,106 @@
+"""-m gpu: FlattenDrawables (rendering/path_tracer.c:692-782) and BakeBrdfFn (math/lighting.c:31-84) on the GPU
+against the oracle, BIT-EXACT; then a scene built from the GPU-flattened arrays renders."""
+import numpy as np
+import pytest
+
+from pim_amd import api, scenes
+from tests.gpu_util import gpu_init, assert_bits_equal
+from tests.util import load_oracle
+from tests.prepare_util import draw_table, oracle_flatten, expected_counts, oracle_brdf_lut
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("count,holes", [(23, True), (400, True), (1, False), (0, False)])
+def test_flatten_bit_exact(count, holes):
+    gpu_init()
+    dr = draw_table(count=count, seed=11 + count, with_holes=holes)
+    V, Mc = expected_counts(dr)
+    assert api.flatten_counts(dr) == (V, Mc)
+    P, N, U, ids, mats = api.flatten(dr)
+    oP, oN, oU, oids, omats = oracle_flatten(load_oracle(portable=True), dr, V, Mc)
+    assert_bits_equal(P, oP, "positions"); assert_bits_equal(N, oN, "normals"); assert_bits_equal(U, oU, "uvs")
+    assert (ids == oids).all()
+    assert bytes(mats)[:48 * Mc] == bytes(omats)[:48 * Mc]
+
+
+def test_flatten_many_instances_of_one_mesh():
+    """the 1M-triangle scene's shape: thousands of entities over two meshes (each mesh is uploaded once)"""
+    gpu_init()
+    rng = np.random.default_rng(3)
+    from tests.prepare_util import mesh4
+    meshes = [mesh4(scenes.box_mesh()), mesh4(scenes.sphere_mesh(24))]
+    count = 300
+    ids = rng.integers(0, 2, count).astype(np.int32)
+    M = np.zeros((count, 4, 4), np.float32)
+    for i in range(count):
+        q = scenes.quat_lookat(scenes.normalize3(rng.normal(size=3).astype(np.float32)), np.array([0, 1, 0], np.float32))
+        c = scenes.trs_matrix(rng.uniform(-50, 50, 3).astype(np.float32), q, rng.uniform(0.5, 2, 3).astype(np.float32))
+        for k in range(4):
+            M[i, k, :3] = c[k]
+        M[i, 3, 3] = 1.0
+    dr = api.Drawables(meshes, ids, M, [api.PimMaterial() for _ in range(count)])
+    V, Mc = api.flatten_counts(dr)
+    assert V == int((ids == 0).sum()) * 36 + int((ids == 1).sum()) * 2208 * 3 and V > 300000
+    P, N, U, mids, _ = api.flatten(dr)
+    oP, oN, oU, oids, _ = oracle_flatten(load_oracle(portable=True), dr, V, Mc)
+    assert_bits_equal(P, oP, "positions"); assert_bits_equal(N, oN, "normals"); assert_bits_equal(U, oU, "uvs")
+    assert (mids == oids).all()
+
+
+def test_flatten_bad_arguments():
+    gpu_init()
+    dr = draw_table(count=4, with_holes=False)
+    dr.mesh_ids[0] = 99
+    with pytest.raises(api.PimGpuError):
+        api.flatten_counts(dr)
+
+
+@pytest.mark.parametrize("sx,sy,passes", [(32, 32, [(0, 64)]), (128, 128, [(0, 16), (16, 26), (26, 36)]), (5, 9, [(0, 3), (3, 3)])])
+def test_brdf_lut_bake_bit_exact(sx, sy, passes):
+    gpu_init()
+    t = np.zeros((sy, sx, 2), np.float32)
+    for prev, num in passes:
+        api.brdf_lut_bake(t, prev, num, seed=21)
+    o = oracle_brdf_lut(load_oracle(portable=True), sx, sy, passes, seed=21)
+    assert_bits_equal(t.reshape(-1, 2), o.reshape(-1, 2), "BRDF table")
+    assert np.isfinite(t).all() and t.max() > 0.5
+
+
+def _desc_with(sc, P, N, U, ids, mats, count, lut):
+    import copy
+    import ctypes
+    d = api.PimSceneDesc.from_buffer_copy(bytes(sc.desc))
+    d.vertCount, d.matCount = P.shape[0], count
+    d.positions, d.normals, d.uvs, d.matIds = P.ctypes.data, N.ctypes.data, U.ctypes.data, ids.ctypes.data
+    d.materials = ctypes.cast(mats, ctypes.c_void_p)
+    d.brdfLut, d.brdfLutSize = lut.ctypes.data, lut.shape[0]
+    return d
+
+
+def test_gpu_prepared_inputs_render_bit_exact():
+    """FlattenDrawables -> PtScene_New -> Pt_Trace with both producers on the GPU: Cornell's draw table flattened and its
+    BRDF table baked on the GPU give a scene whose image equals the oracle's on the same inputs, and whose vertices are
+    the harness' own (numpy) flatten up to its last-bit differences"""
+    gpu_init()
+    sc = scenes.cornell_box()
+    dr = scenes.drawables_of(sc)
+    P, N, U, ids, mats = api.flatten(dr)
+    assert P.shape == sc.positions.shape and np.allclose(P, sc.positions, rtol=0, atol=4e-6)
+    assert np.allclose(N, sc.normals, rtol=0, atol=4e-6) and (U == sc.uvs).all()
+    lut = np.zeros((32, 32, 2), np.float32)
+    api.brdf_lut_bake(lut, 0, 64, seed=7)
+    d = _desc_with(sc, P, N, U, ids, mats, len(sc.entities), lut)
+    g = api.Scene(d)
+    from tests.util import OracleScene
+    o = OracleScene(d, accel=1)
+    W, H = 96, 54
+    tr = api.Trace(W, H)
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dof_g, dof_o = scenes.default_dof(), scenes.default_dof()
+    for s in range(2):
+        tr.trace(g, scenes.pt_test_camera(), dof_g, scenes.trace_params(s, max_bounces=4))
+        o.trace_image(img, W, H, scenes.pt_test_camera(), dof_o, scenes.trace_params(s, max_bounces=4))
+    assert_bits_equal(tr.download()[0], img[0], "colour of the GPU-prepared scene")
+    assert img[0].mean() > 0.01
+    g.close()
