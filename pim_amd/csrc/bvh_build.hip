@@ -463,12 +463,72 @@ __global__ __launch_bounds__(256) void k_emit_tris(const v4* __restrict__ positi
     tris[(size_t)j * 3 + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
 }
 
+/*
+ * 128-byte fp32 node -> 64-byte compressed node (layout in pt_device.h).  Per axis the grid step is the smallest
+ * power of two with 255 steps >= the extent of the union box; planes are rounded outwards in double precision
+ * (differences of floats and power-of-two scalings are exact there), so the compressed box contains the fp32 one.
+ */
+__device__ __forceinline__ float quant_step(float extent)
+{
+    const float x = extent * (1.0f / 255.0f) * 1.000001f;
+    if (!(x > 1e-30f)) return __uint_as_float(37u << 23);      /* flat node: a tiny step (2^-90) covers it with q = 0 or 1 */
+    const uint32_t b = __float_as_uint(x);
+    uint32_t e = b >> 23;                                    /* x > 0, finite */
+    if (b & 0x7fffffu) ++e;
+    return __uint_as_float(e << 23);
+}
+
+__global__ __launch_bounds__(256) void k_compress_nodes(const float4* __restrict__ wide, int32_t nodeCount, uint4* __restrict__ cnodes)
+{
+    const int32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nodeCount) return;
+    const float4* q = wide + (size_t)w * 8;
+    float lo[3][4], hi[3][4]; int32_t child[4];
+    for (int a = 0; a < 3; ++a)
+    {
+        const float4 l = q[a], h = q[3 + a];
+        lo[a][0] = l.x; lo[a][1] = l.y; lo[a][2] = l.z; lo[a][3] = l.w;
+        hi[a][0] = h.x; hi[a][1] = h.y; hi[a][2] = h.z; hi[a][3] = h.w;
+    }
+    const float4 ch = q[6];
+    child[0] = __float_as_int(ch.x); child[1] = __float_as_int(ch.y); child[2] = __float_as_int(ch.z); child[3] = __float_as_int(ch.w);
+    float org[3], step[3]; uint32_t qlo[3], qhi[3];
+    for (int a = 0; a < 3; ++a)
+    {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int k = 0; k < 4; ++k) if (child[k] != PT_BVH_EMPTY) { mn = fminf(mn, lo[a][k]); mx = fmaxf(mx, hi[a][k]); }
+        if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }          /* no children at all (empty scene) */
+        org[a] = mn;
+        step[a] = quant_step(mx - mn);
+        uint32_t pl = 0, ph = 0;
+        for (int k = 0; k < 4; ++k)
+        {
+            uint32_t a0 = 255u, a1 = 0u;                      /* empty slot: inverted */
+            if (child[k] != PT_BVH_EMPTY)
+            {
+                const double inv = 1.0 / (double)step[a];
+                double f0 = floor(((double)lo[a][k] - (double)mn) * inv), f1 = ceil(((double)hi[a][k] - (double)mn) * inv);
+                f0 = f0 < 0.0 ? 0.0 : (f0 > 255.0 ? 255.0 : f0);
+                f1 = f1 < 0.0 ? 0.0 : (f1 > 255.0 ? 255.0 : f1);
+                a0 = (uint32_t)f0; a1 = (uint32_t)f1;
+            }
+            pl |= a0 << (8 * k); ph |= a1 << (8 * k);
+        }
+        qlo[a] = pl; qhi[a] = ph;
+    }
+    uint4* c = cnodes + (size_t)w * 4;
+    c[0] = make_uint4(__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]), __float_as_uint(step[0]));
+    c[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    c[2] = make_uint4(qhi[1], qhi[2], __float_as_uint(step[1]), __float_as_uint(step[2]));
+    c[3] = make_uint4((uint32_t)child[0], (uint32_t)child[1], (uint32_t)child[2], (uint32_t)child[3]);
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 
 void BvhStorage::release()
 {
-    hipFree(nodes); hipFree(tris); hipFree(scratch);
-    nodes = nullptr; tris = nullptr; scratch = nullptr; scratchBytes = 0; capacityTris = 0;
+    hipFree(nodes); hipFree(cnodes); hipFree(tris); hipFree(scratch);
+    nodes = nullptr; cnodes = nullptr; tris = nullptr; scratch = nullptr; scratchBytes = 0; capacityTris = 0;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -494,6 +554,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     {
         b->release();
         if (hipMalloc(&b->nodes, sizeof(float4) * 8 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
+        if (hipMalloc(&b->cnodes, sizeof(uint4) * 4 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
         if (hipMalloc(&b->tris, sizeof(float4) * 3 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
         if (hipMalloc(&b->scratch, need) != hipSuccess) return PIMGPU_E_NOMEM;
         b->capacityTris = cap; b->scratchBytes = need;
@@ -519,6 +580,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     if (n <= PT_LEAF_MAX)
     {
         k_emit_single<<<1, 64, 0, stream>>>(n, triLo, triHi, b->nodes);
+        k_compress_nodes<<<1, 256, 0, stream>>>(b->nodes, 1, b->cnodes);
         if (n > 0) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, nullptr, n, b->tris);
         return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
     }
@@ -563,6 +625,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             if (hostSnap[l + 1] == hostSnap[l]) { done = true; b->depth = l; b->nodeCount = hostSnap[l]; break; }
         }
     }
+    k_compress_nodes<<<(b->nodeCount + 255) / 256, 256, 0, stream>>>(b->nodes, b->nodeCount, b->cnodes);
     return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
 }
 
@@ -640,6 +703,37 @@ int bvh_validate(const BvhStorage* b, hipStream_t stream, std::string* why)
                             if (!(pp[a] >= child.lo[a] && pp[a] <= child.hi[a]))
                             { snprintf(buf, sizeof(buf), "node %d slot %d: triangle slot %u vertex %d (%g) outside the leaf box [%g,%g] on axis %d", it.node, k, t, v, pp[a], child.lo[a], child.hi[a], a); *why = buf; return PIMGPU_E_STATE; }
                     }
+            }
+        }
+    }
+    /* compressed copy: same children, every decoded box contains the fp32 box */
+    {
+        std::vector<uint4> cn((size_t)b->nodeCount * 4);
+        if (hipMemcpy(cn.data(), b->cnodes, sizeof(uint4) * cn.size(), hipMemcpyDeviceToHost) != hipSuccess) { *why = "copy of compressed nodes failed"; return PIMGPU_E_DEVICE; }
+        for (int32_t w = 0; w < b->nodeCount; ++w)
+        {
+            if (!seenNode[(size_t)w]) continue;
+            const float4* q = &nodes[(size_t)w * 8];
+            const uint4* c = &cn[(size_t)w * 4];
+            float org[3], step[3];
+            __builtin_memcpy(&org[0], &c[0].x, 4); __builtin_memcpy(&org[1], &c[0].y, 4); __builtin_memcpy(&org[2], &c[0].z, 4);
+            __builtin_memcpy(&step[0], &c[0].w, 4); __builtin_memcpy(&step[1], &c[2].z, 4); __builtin_memcpy(&step[2], &c[2].w, 4);
+            const uint32_t ql[3] = { c[1].x, c[1].y, c[1].z }, qh[3] = { c[1].w, c[2].x, c[2].y };
+            const uint32_t cc[4] = { c[3].x, c[3].y, c[3].z, c[3].w };
+            const float ch[4] = { q[6].x, q[6].y, q[6].z, q[6].w };
+            for (int k = 0; k < 4; ++k)
+            {
+                uint32_t cf; __builtin_memcpy(&cf, &ch[k], 4);
+                if (cf != cc[k]) { snprintf(buf, sizeof(buf), "compressed node %d slot %d: child %08x != %08x", w, k, cc[k], cf); *why = buf; return PIMGPU_E_STATE; }
+                if ((int32_t)cf == PT_BVH_EMPTY) continue;
+                for (int a = 0; a < 3; ++a)
+                {
+                    const float* fl = &q[a].x; const float* fh = &q[3 + a].x;
+                    const double dl = (double)org[a] + (double)((ql[a] >> (8 * k)) & 255u) * (double)step[a];
+                    const double dh = (double)org[a] + (double)((qh[a] >> (8 * k)) & 255u) * (double)step[a];
+                    if (!(dl <= (double)fl[k] && dh >= (double)fh[k]))
+                    { snprintf(buf, sizeof(buf), "compressed node %d slot %d axis %d: [%.9g,%.9g] does not contain [%.9g,%.9g]", w, k, a, dl, dh, fl[k], fh[k]); *why = buf; return PIMGPU_E_STATE; }
+                }
             }
         }
     }

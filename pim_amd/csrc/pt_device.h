@@ -53,6 +53,17 @@ struct DGrid { v4 lo, hi; int32_t sx, sy, sz; float cellsPerMeter; };
  * child >= 0: inner node index; child < 0 and != PT_BVH_EMPTY: leaf, ~child = (first << 3) | (count - 1),
  * first = index of the leaf's first triangle in tris[] (3 float4 per triangle, leaf order:
  * p0.xyz + primID bits in w, p1.xyz, p2.xyz); empty slots have an inverted box and PT_BVH_EMPTY.
+ *
+ * The batched traversal kernel reads a COMPRESSED copy of the same tree, 64 bytes per node (4 x 16-B loads per
+ * visit instead of 7: the kernel is bound by the vector L1's one-lookup-per-lane-per-cycle rate, not by bytes):
+ *
+ *   uint4 c[0] = (lo.x, lo.y, lo.z, scale.x)   floats: minimum corner of the union of the child boxes, grid step
+ *   uint4 c[1] = (qlo.x, qlo.y, qlo.z, qhi.x)  each dword = one plane of the 4 children, one byte per child
+ *   uint4 c[2] = (qhi.y, qhi.z, scale.y, scale.z)
+ *   uint4 c[3] = child[0..3]                   as above
+ *
+ * child plane = lo + q * scale with q in 0..255 and scale a power of two (so q * scale is exact), rounded
+ * outwards (floor / ceil), i.e. every compressed box contains its fp32 box; empty slots hold qlo = 255, qhi = 0.
  */
 #define PT_BVH_EMPTY  ((int32_t)0x80000000)
 #ifndef PT_LEAF_MAX
@@ -62,6 +73,7 @@ struct DGrid { v4 lo, hi; int32_t sx, sy, sz; float cellsPerMeter; };
 struct DBvh
 {
     const float4* nodes;     /* 8 float4 per node */
+    const uint4* cnodes;     /* 4 uint4 per node: the compressed copy */
     const float4* tris;      /* 3 float4 per triangle, leaf order */
     int32_t nodeCount;
     int32_t triCount;

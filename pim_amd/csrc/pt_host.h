@@ -14,6 +14,7 @@ namespace pt {
 struct BvhStorage
 {
     float4* nodes = nullptr;
+    uint4* cnodes = nullptr;            /* 64-byte compressed nodes (pt_device.h) */
     float4* tris = nullptr;
     void* scratch = nullptr;
     size_t scratchBytes = 0;
@@ -22,7 +23,7 @@ struct BvhStorage
     int32_t nodeCount = 0;
     int32_t depth = 0;                  /* levels of the 4-wide tree of the last build */
     void release();
-    DBvh view() const { DBvh b; b.nodes = nodes; b.tris = tris; b.nodeCount = nodeCount; b.triCount = triCount; return b; }
+    DBvh view() const { DBvh b; b.nodes = nodes; b.cnodes = cnodes; b.tris = tris; b.nodeCount = nodeCount; b.triCount = triCount; return b; }
 };
 
 /* bvh_build.hip: full (re)build from device positions (float4[3*triCount]) on stream; returns with the stream drained */

@@ -18,17 +18,27 @@ static constexpr int kTraceThreads = 256;
 static constexpr int kTraceBlocksPerCU = 8;
 
 /*
- * The kernel is a per-lane state machine, not a per-ray function call: every trip of the wave's loop
- * a lane tests ONE node (4 boxes), then ONE triangle, then pops -- whichever its state asks for -- so
- * a wave never sits through a whole leaf (up to PT_LEAF_MAX triangles) for the sake of one lane, and
- * lanes whose ray has finished are REFILLED from the wave's own contiguous slice of the ray array once
- * PT_REFILL_IDLE of them are idle, instead of idling until the slowest ray of the wave is done.
- * `cur` holds the state: >= 0 node index; < 0 leaf code ~((first << 3) | (count - 1)), stepped by
- * code + 7 per triangle (first + 1, count - 1); PT_BVH_EMPTY = "pop next".
- * Which lane traces which ray does not influence the ray's result (traverse.h contract).
+ * The kernel is a per-lane state machine, not a per-ray function call.  Every trip of the wave's loop a lane
+ *   A  tests ONE node (4 boxes, the hit children sorted by entry distance, the far ones pushed),
+ *   S  puts a leaf it has reached aside in `leaf` and pops the next stack entry, so that it has a node again
+ *      for the next trip (a second leaf reached while the first is still waiting stalls the lane),
+ *   B  tests ONE triangle of the leaf it has put aside -- but only on trips where PT_TRI_VOTE lanes of the wave
+ *      have one waiting, or no lane has a node left.
+ * Nodes are tested about four times as often as triangles; running the triangle code on every trip for the few
+ * lanes that are at a leaf costs the whole wave its instructions, so leaves are postponed until enough of them
+ * have gathered (Aila & Laine's speculative traversal).  Lanes whose ray has finished are REFILLED from the wave's
+ * own contiguous slice of the ray array once PT_REFILL_IDLE of them are idle, instead of idling until the slowest
+ * ray of the wave is done.
+ * `cur`: >= 0 node index; < 0 leaf code ~((first << 3) | (count - 1)); PT_BVH_EMPTY = nothing.  `leaf`: the leaf
+ * put aside, stepped by code + 7 per triangle (first + 1, count - 1), PT_BVH_EMPTY = none.
+ * Which lane traces which ray, and in which order a ray meets its nodes and triangles, does not influence the
+ * ray's result (traverse.h contract).
  */
 #ifndef PT_REFILL_IDLE
 #define PT_REFILL_IDLE 16
+#endif
+#ifndef PT_TRI_VOTE
+#define PT_TRI_VOTE 16
 #endif
 
 template <bool ANY, bool COUNT>
@@ -39,9 +49,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     __shared__ unsigned long long sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
     LdsStack st;
-    st.lds = sStack + threadIdx.x; st.ldsStride = kTraceThreads;
+    st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = kTraceThreads;
     st.spillStride = (int64_t)gridDim.x * kTraceThreads;
-    st.spill = spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x);
+    st.spill = (glb_u64*)(spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x));
     st.init();
     bool overflow = false;
     uint32_t cNodes = 0, cTris = 0, cRays = 0, cWorst = 0, rayNodes = 0;
@@ -54,12 +64,13 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     const int32_t sliceEnd = (int32_t)min((int64_t)n, per * (wave + 1));
 
     const float4* __restrict__ nodes = bvh.nodes;
+    const uint4* __restrict__ cnodes = bvh.cnodes;
     const float4* __restrict__ tris = bvh.tris;
 
     bool active = false;
-    int32_t ri = 0, cur = PT_BVH_EMPTY;
-    float ix = 0.0f, iy = 0.0f, iz = 0.0f, tNear = 0.0f;
-    RayPad pad = {};
+    int32_t ri = 0, cur = PT_BVH_EMPTY, leaf = PT_BVH_EMPTY;
+    float tNear = 0.0f;
+    RaySlabQ sl = {};
     RayPre r = {};
     DHit h = {};
 
@@ -80,10 +91,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                     if (d.w > o.w)
                     {
                         r = ray_pre(o.x, o.y, o.z, d.x, d.y, d.z);
-                        pad = ray_pad(o.x, o.y, o.z, nodes[7].x);
+                        sl = ray_slab_q(o.x, o.y, o.z, d.x, d.y, d.z, nodes[7].x);
                         tNear = o.w;
-                        ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
-                        cur = 0; active = true;
+                        cur = 0; leaf = PT_BVH_EMPTY; active = true;
                         if (COUNT) { ++cRays; rayNodes = 0; }
                     }
                     else
@@ -101,36 +111,32 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
         }
         for (;;)
         {
-            /* A: one node */
+            /* A: one node (compressed, 4 x 16 bytes) */
             if (active && cur >= 0)
             {
                 if (COUNT) { ++cNodes; ++rayNodes; }
-                const float4* q = nodes + (size_t)cur * 8;
-                const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-                const float4 ch = q[6];
+                const uint4* q = cnodes + (size_t)cur * 4;
+                const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
                 float d[4]; int32_t c[4];
-                c[0] = __float_as_int(ch.x); c[1] = __float_as_int(ch.y); c[2] = __float_as_int(ch.z); c[3] = __float_as_int(ch.w);
-                /* slab distances of the 4 boxes, two boxes per packed instruction (same IEEE operations per element) */
-                const f2 oxp = { pad.xp, pad.xp }, oyp = { pad.yp, pad.yp }, ozp = { pad.zp, pad.zp };
-                const f2 oxm = { pad.xm, pad.xm }, oym = { pad.ym, pad.ym }, ozm = { pad.zm, pad.zm };
-                const f2 vix = { ix, ix }, viy = { iy, iy }, viz = { iz, iz };
-                f2 ax[2], bx[2], ay[2], by[2], az[2], bz[2];
-                ax[0] = ((f2){ lox.x, lox.y } - oxp) * vix; ax[1] = ((f2){ lox.z, lox.w } - oxp) * vix;
-                bx[0] = ((f2){ hix.x, hix.y } - oxm) * vix; bx[1] = ((f2){ hix.z, hix.w } - oxm) * vix;
-                ay[0] = ((f2){ loy.x, loy.y } - oyp) * viy; ay[1] = ((f2){ loy.z, loy.w } - oyp) * viy;
-                by[0] = ((f2){ hiy.x, hiy.y } - oym) * viy; by[1] = ((f2){ hiy.z, hiy.w } - oym) * viy;
-                az[0] = ((f2){ loz.x, loz.y } - ozp) * viz; az[1] = ((f2){ loz.z, loz.w } - ozp) * viz;
-                bz[0] = ((f2){ hiz.x, hiz.y } - ozm) * viz; bz[1] = ((f2){ hiz.z, hiz.w } - ozm) * viz;
+                c[0] = (int32_t)w3.x; c[1] = (int32_t)w3.y; c[2] = (int32_t)w3.z; c[3] = (int32_t)w3.w;
+                /* plane parameter = q * (step / d) + (origin plane parameter); near / far planes picked per ray octant,
+                 * one select per packed dword of 4 children */
+                const float ax = __uint_as_float(w0.w) * sl.ix, ay = __uint_as_float(w2.z) * sl.iy, az = __uint_as_float(w2.w) * sl.iz;
+                const float bnx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.nx), bfx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.fx);
+                const float bny = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.ny), bfy = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.fy);
+                const float bnz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.nz), bfz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.fz);
+                const bool px = sl.ix >= 0.0f, py = sl.iy >= 0.0f, pz = sl.iz >= 0.0f;
+                const uint32_t qnx = px ? w1.x : w1.w, qfx = px ? w1.w : w1.x;
+                const uint32_t qny = py ? w1.y : w2.x, qfy = py ? w2.x : w1.y;
+                const uint32_t qnz = pz ? w1.z : w2.y, qfz = pz ? w2.y : w1.z;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
-                    const float axk = ax[k >> 1][k & 1], bxk = bx[k >> 1][k & 1];
-                    const float ayk = ay[k >> 1][k & 1], byk = by[k >> 1][k & 1];
-                    const float azk = az[k >> 1][k & 1], bzk = bz[k >> 1][k & 1];
-                    float t0 = fmaxf(fmaxf(fminf(axk, bxk), fminf(ayk, byk)), fmaxf(fminf(azk, bzk), tNear));
-                    float t1 = fminf(fminf(fmaxf(axk, bxk), fmaxf(ayk, byk)), fmaxf(azk, bzk)) * 1.0000004f;   /* conservative slab (Ize 2013) */
-                    t1 = fminf(t1, h.t);
-                    /* empty slots carry an inverted box, which the min/max slab test would read as infinite: test the tag */
+                    const float tnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 255u), ax, bnx), tfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 255u), ax, bfx);
+                    const float tny = __builtin_fmaf((float)((qny >> (8 * k)) & 255u), ay, bny), tfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 255u), ay, bfy);
+                    const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 255u), az, bnz), tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 255u), az, bfz);
+                    const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tNear));
+                    const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
                     d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
                 }
                 /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
@@ -142,42 +148,45 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 overflow |= !st.push3(d[1], c[1], d[2], c[2], d[3], c[3]);
                 cur = (d[0] < __builtin_inff()) ? c[0] : PT_BVH_EMPTY;
             }
-            /* B: one triangle of the current leaf */
-            bool finished = false;
-            if (active && cur < 0 && cur != PT_BVH_EMPTY)
+            /* S: put a reached leaf aside, then pop (culling entries that start beyond the current closest hit) */
+            if (active && cur < 0)
             {
-                if (COUNT) ++cTris;
-                const uint32_t code = (uint32_t)~cur;
-                const float4* tp = tris + (size_t)(code >> 3) * 3;
-                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                float t, u, v;
-                if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v))
-                {
-                    hit_consider(h, __float_as_int(p0.w), t, u, v);
-                    if (ANY) finished = true;
-                }
-                cur = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
-            }
-            /* C: pop, culling entries that start beyond the current closest hit */
-            if (active && (finished || cur == PT_BVH_EMPTY))
-            {
-                if (!finished)
+                if (cur != PT_BVH_EMPTY && leaf == PT_BVH_EMPTY) { leaf = cur; cur = PT_BVH_EMPTY; }
+                if (cur == PT_BVH_EMPTY)
                 {
                     float t; int32_t c;
-                    finished = true;
                     while (st.pop(&t, &c))
                     {
-                        if (t <= h.t) { cur = c; finished = false; break; }
+                        if (t <= h.t) { cur = c; break; }
                     }
                 }
-                if (finished)
+            }
+            /* B: one triangle of the leaf put aside, when enough lanes have one or none has a node */
+            {
+                const unsigned long long leafMask = __ballot(active && leaf != PT_BVH_EMPTY);
+                const unsigned long long nodeMask = __ballot(active && cur >= 0);
+                if (leafMask != 0ull && ((int32_t)__popcll(leafMask) >= PT_TRI_VOTE || nodeMask == 0ull))
                 {
-                    if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
-                    else hits[ri] = h;
-                    if (COUNT) cWorst = max(cWorst, rayNodes);
-                    st.init();
-                    active = false;
+                    if (active && leaf != PT_BVH_EMPTY)
+                    {
+                        if (COUNT) ++cTris;
+                        const uint32_t code = (uint32_t)~leaf;
+                        const float4* tp = tris + (size_t)(code >> 3) * 3;
+                        const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                        float t, u, v;
+                        if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v)) hit_consider(h, __float_as_int(p0.w), t, u, v);
+                        leaf = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
+                    }
                 }
+            }
+            /* done: nothing in hand, nothing aside, nothing on the stack (any-hit: the first accepted triangle) */
+            if (active && ((cur == PT_BVH_EMPTY && leaf == PT_BVH_EMPTY) || (ANY && h.prim >= 0)))
+            {
+                if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
+                else hits[ri] = h;
+                if (COUNT) cWorst = max(cWorst, rayNodes);
+                st.init();
+                active = false;
             }
             const int32_t idleCount = (int32_t)__popcll(__ballot(!active));
             if (idleCount == 64 || (idleCount >= PT_REFILL_IDLE && cursor < sliceEnd)) break;

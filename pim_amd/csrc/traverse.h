@@ -71,6 +71,43 @@ __device__ __forceinline__ RayPad ray_pad(float ox, float oy, float oz, float sc
     return p;
 }
 
+/*
+ * Slab test in fused form: the entry/exit parameter of a plane is fma(plane, 1/d, c) with c = -(o +- e) / d computed
+ * once per ray, one v_pk_fma_f32 for two boxes.  The rounding of c moves the plane by <= 2^-24 |o| and the single
+ * rounding of the fma by <= 2^-24 |plane - o|, both far inside the padding e, so the test stays conservative without
+ * a widening factor on the exit distance.  1/d is clamped to +-1e30 (a zero or denormal component would give
+ * inf - inf = NaN in the fused form); such a ray is parallel to the slab and the test then reads "inside or outside".
+ */
+struct RaySlab { float ix, iy, iz, lx, ly, lz, hx, hy, hz; };
+/* the same for compressed nodes (pt_device.h): per axis the NEAR plane of a box is its lo plane when 1/d >= 0 and
+ * its hi plane otherwise, so the constants are kept per near / far side: plane parameter = fma(plane, i, n or f) */
+struct RaySlabQ { float ix, iy, iz, nx, ny, nz, fx, fy, fz; };
+__device__ __forceinline__ float slab_rcp(float d)
+{
+    const float i = 1.0f / d;
+    return fabsf(i) <= 1e30f ? i : __builtin_copysignf(1e30f, d);
+}
+__device__ __forceinline__ RaySlab ray_slab(float ox, float oy, float oz, float dx, float dy, float dz, float sceneMaxAbs)
+{
+    const RayPad p = ray_pad(ox, oy, oz, sceneMaxAbs);
+    RaySlab s;
+    s.ix = slab_rcp(dx); s.iy = slab_rcp(dy); s.iz = slab_rcp(dz);
+    s.lx = -(p.xp * s.ix); s.ly = -(p.yp * s.iy); s.lz = -(p.zp * s.iz);
+    s.hx = -(p.xm * s.ix); s.hy = -(p.ym * s.iy); s.hz = -(p.zm * s.iz);
+    return s;
+}
+
+__device__ __forceinline__ RaySlabQ ray_slab_q(float ox, float oy, float oz, float dx, float dy, float dz, float sceneMaxAbs)
+{
+    const RaySlab s = ray_slab(ox, oy, oz, dx, dy, dz, sceneMaxAbs);
+    RaySlabQ q;
+    q.ix = s.ix; q.iy = s.iy; q.iz = s.iz;
+    q.nx = s.ix >= 0.0f ? s.lx : s.hx; q.fx = s.ix >= 0.0f ? s.hx : s.lx;
+    q.ny = s.iy >= 0.0f ? s.ly : s.hy; q.fy = s.iy >= 0.0f ? s.hy : s.ly;
+    q.nz = s.iz >= 0.0f ? s.lz : s.hz; q.fz = s.iz >= 0.0f ? s.hz : s.lz;
+    return q;
+}
+
 /* true and t,u,v written when the triangle is hit inside (tNear, tFar] */
 __device__ __forceinline__ bool tri_test(const RayPre& r, float4 p0, float4 p1, float4 p2, float tNear, float tFar,
     float* tOut, float* uOut, float* vOut)
@@ -140,10 +177,14 @@ struct TrivialStack
 };
 
 /* entries are one 64-bit word: child in the high half, entry distance (float bits) in the low half */
+/* typed address spaces: the LDS part is read and written with ds_* instructions, the spill part with global_*,
+ * and the compiler cannot fold the two into one generic-address access */
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(1))) unsigned long long glb_u64;
 struct LdsStack
 {
-    unsigned long long* lds;    /* &shared[threadIdx.x], stride ldsStride */
-    unsigned long long* spill;  /* &spill[global lane slot], stride spillStride */
+    lds_u64* lds;               /* &shared[threadIdx.x], stride ldsStride */
+    glb_u64* spill;             /* &spill[global lane slot], stride spillStride */
     int ldsStride;
     int64_t spillStride;
     int sp;
@@ -161,9 +202,10 @@ struct LdsStack
     {
         if (sp == 0) return false;
         --sp;
-        unsigned long long v;
-        if (sp < PT_STACK_LDS) v = lds[sp * ldsStride];                        /* two typed loads: no generic-address access */
-        else v = spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
+        /* the LDS read is unconditional (clamped slot) and the rare spill read sits under its own branch, so the
+         * common case is one ds_read_b64 and never a generic-address load */
+        unsigned long long v = lds[(sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1) * ldsStride];
+        if (sp >= PT_STACK_LDS) v = spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
         *t = __uint_as_float((uint32_t)v); *c = (int32_t)(v >> 32);
         return true;
     }
