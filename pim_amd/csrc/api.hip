@@ -173,7 +173,15 @@ int pimgpu_work_counters(int enable, uint64_t* out)
     int rc = check_ready(); if (rc) return rc;
     PT_HIP(hipStreamSynchronize(g_lib.stream));
     if (out) PT_HIP(hipMemcpy(out, g_lib.trace.work, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    PT_HIP(hipMemset(g_lib.trace.work, 0, 4 * sizeof(uint64_t)));
+    if (getenv("PIMGPU_TRACE_DIAG"))
+    {
+        uint64_t w[12] = {};
+        PT_HIP(hipMemcpy(w, g_lib.trace.work, sizeof(w), hipMemcpyDeviceToHost));
+        if (w[2]) fprintf(stderr, "[trace diag] rays %llu  trips(wave) %llu  A-exec %llu  B-exec %llu  pop-iter(wave) %llu  pop-lanes %llu  | per 64 rays: trips %.1f A %.1f B %.1f popIter %.1f\n",
+            (unsigned long long)w[2], (unsigned long long)w[4], (unsigned long long)w[5], (unsigned long long)w[6], (unsigned long long)w[7], (unsigned long long)w[8],
+            64.0 * w[4] / w[2], 64.0 * w[5] / w[2], 64.0 * w[6] / w[2], 64.0 * w[7] / w[2]);
+    }
+    PT_HIP(hipMemset(g_lib.trace.work, 0, 12 * sizeof(uint64_t)));
     g_lib.trace.counting = enable != 0;
     return PIMGPU_OK;
 }

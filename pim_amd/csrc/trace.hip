@@ -37,6 +37,9 @@ static constexpr int kTraceBlocksPerCU = 8;
 #ifndef PT_REFILL_IDLE
 #define PT_REFILL_IDLE 16
 #endif
+#ifndef PT_POP_MAX
+#define PT_POP_MAX 1
+#endif
 #ifndef PT_TRI_VOTE
 #define PT_TRI_VOTE 16
 #endif
@@ -55,6 +58,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     st.init();
     bool overflow = false;
     uint32_t cNodes = 0, cTris = 0, cRays = 0, cWorst = 0, rayNodes = 0;
+    uint32_t cTrips = 0, cExecA = 0, cExecB = 0, cPopIter = 0, cPopLanes = 0;     /* counting build: wave-level executions of each section */
 
     /* this wave's slice of the rays: contiguous, a multiple of 64 long */
     const int32_t wavesTotal = (int32_t)gridDim.x * (kTraceThreads / 64);
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     const float4* __restrict__ tris = bvh.tris;
 
     bool active = false;
-    int32_t ri = 0, cur = PT_BVH_EMPTY, leaf = PT_BVH_EMPTY;
+    int32_t ri = -1, cur = PT_BVH_EMPTY, leaf = PT_BVH_EMPTY;      /* ri >= 0 on an inactive lane: a finished ray whose record is not stored yet */
+    float hDet = 1.0f;                                              /* h.u, h.v hold the numerators V, W until the record is stored */
     float tNear = 0.0f;
     RaySlabQ sl = {};
     RayPre r = {};
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                     else
                     {
                         if (ANY) occluded[ri] = 0; else hits[ri] = h;
+                        ri = -1;
                     }
                 }
                 cursor = min(sliceEnd, cursor + (int32_t)__popcll(idle));
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
         }
         for (;;)
         {
+            if (COUNT) { ++cTrips; if (__ballot(active && cur >= 0) != 0ull) ++cExecA; }
             /* A: one node (compressed, 4 x 16 bytes) */
             if (active && cur >= 0)
             {
@@ -129,6 +136,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 const uint32_t qnx = px ? w1.x : w1.w, qfx = px ? w1.w : w1.x;
                 const uint32_t qny = py ? w1.y : w2.x, qfy = py ? w2.x : w1.y;
                 const uint32_t qnz = pz ? w1.z : w2.y, qfz = pz ? w2.y : w1.z;
+                /* Empty slots are inverted on the grid (near 255, far 0) and reject themselves; should one slip through in a
+                 * node flat on every axis, its PT_BVH_EMPTY is read as "nothing" when it is popped */
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                     const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 255u), az, bnz), tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 255u), az, bfz);
                     const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tNear));
                     const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
-                    d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
+                    d[k] = (t0 <= t1) ? t0 : __builtin_inff();
                 }
                 /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
                 PT_SWAP_IF(d[0], c[0], d[1], c[1]);
@@ -154,10 +163,17 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 if (cur != PT_BVH_EMPTY && leaf == PT_BVH_EMPTY) { leaf = cur; cur = PT_BVH_EMPTY; }
                 if (cur == PT_BVH_EMPTY)
                 {
+                    /* at most PT_POP_MAX entries per trip: an entry that starts beyond the closest hit is dropped and the
+                     * lane tries again on the next trip (a loop until one survives keeps the whole wave waiting on LDS) */
                     float t; int32_t c;
-                    while (st.pop(&t, &c))
+#pragma unroll
+                    for (int k = 0; k < PT_POP_MAX; ++k)
                     {
-                        if (t <= h.t) { cur = c; break; }
+                        if (cur == PT_BVH_EMPTY && st.pop(&t, &c))
+                        {
+                            if (COUNT) { ++cPopLanes; if ((int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0) ++cPopIter; }
+                            if (t <= h.t) cur = c;
+                        }
                     }
                 }
             }
@@ -167,29 +183,44 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 const unsigned long long nodeMask = __ballot(active && cur >= 0);
                 if (leafMask != 0ull && ((int32_t)__popcll(leafMask) >= PT_TRI_VOTE || nodeMask == 0ull))
                 {
+                    if (COUNT) ++cExecB;
                     if (active && leaf != PT_BVH_EMPTY)
                     {
                         if (COUNT) ++cTris;
                         const uint32_t code = (uint32_t)~leaf;
                         const float4* tp = tris + (size_t)(code >> 3) * 3;
                         const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                        float t, u, v;
-                        if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v)) hit_consider(h, __float_as_int(p0.w), t, u, v);
+                        float t, vn, wn, det;
+                        if (tri_test_raw(r, p0, p1, p2, tNear, h.t, &t, &vn, &wn, &det))
+                        {
+                            const int32_t prim = __float_as_int(p0.w);
+                            if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim))) { h.prim = prim; h.t = t; h.u = vn; h.v = wn; hDet = det; }
+                        }
                         leaf = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
                     }
                 }
             }
             /* done: nothing in hand, nothing aside, nothing on the stack (any-hit: the first accepted triangle) */
-            if (active && ((cur == PT_BVH_EMPTY && leaf == PT_BVH_EMPTY) || (ANY && h.prim >= 0)))
+            if (active && ((cur == PT_BVH_EMPTY && leaf == PT_BVH_EMPTY && st.sp == 0) || (ANY && h.prim >= 0)))
             {
-                if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
-                else hits[ri] = h;
                 if (COUNT) cWorst = max(cWorst, rayNodes);
                 st.init();
-                active = false;
+                active = false;             /* the record is stored at the next refill */
             }
             const int32_t idleCount = (int32_t)__popcll(__ballot(!active));
             if (idleCount == 64 || (idleCount >= PT_REFILL_IDLE && cursor < sliceEnd)) break;
+        }
+        /* store the records of the rays that finished during this round of trips: the two barycentric divisions and the store
+         * run here, once per batch of finished lanes, not on every trip on which some lane finishes */
+        if (!active && ri >= 0)
+        {
+            if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
+            else
+            {
+                if (h.prim >= 0) { h.u = h.u / hDet; h.v = h.v / hDet; }
+                hits[ri] = h;
+            }
+            ri = -1;
         }
     }
     if (overflow) atomicOr(status, 1u);
@@ -200,6 +231,12 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
         atomicAdd(&work[1], (unsigned long long)cTris);
         atomicAdd(&work[2], (unsigned long long)cRays);
         atomicMax(&work[3], (unsigned long long)cWorst);           /* most nodes any single ray fetched */
+        if ((threadIdx.x & 63) == 0)
+        {
+            atomicAdd(&work[4], (unsigned long long)cTrips); atomicAdd(&work[5], (unsigned long long)cExecA);
+            atomicAdd(&work[6], (unsigned long long)cExecB);
+        }
+        atomicAdd(&work[7], (unsigned long long)cPopIter); atomicAdd(&work[8], (unsigned long long)cPopLanes);
     }
 }
 

@@ -84,7 +84,7 @@ struct RaySlab { float ix, iy, iz, lx, ly, lz, hx, hy, hz; };
 struct RaySlabQ { float ix, iy, iz, nx, ny, nz, fx, fy, fz; };
 __device__ __forceinline__ float slab_rcp(float d)
 {
-    const float i = 1.0f / d;
+    const float i = __builtin_amdgcn_rcpf(d);               /* 1 ulp is plenty for a padded box test */
     return fabsf(i) <= 1e30f ? i : __builtin_copysignf(1e30f, d);
 }
 __device__ __forceinline__ RaySlab ray_slab(float ox, float oy, float oz, float dx, float dy, float dz, float sceneMaxAbs)
@@ -143,6 +143,43 @@ __device__ __forceinline__ bool tri_test(const RayPre& r, float4 p0, float4 p1, 
     *tOut = t;
     *uOut = V / det;
     *vOut = W / det;
+    return true;
+}
+
+/* the same test with the two barycentric divisions left to the caller: u = V / det, v = W / det (the batched kernel
+ * divides once per ray, for the hit that won, instead of once per accepted triangle) */
+__device__ __forceinline__ bool tri_test_raw(const RayPre& r, float4 p0, float4 p1, float4 p2, float tNear, float tFar,
+    float* tOut, float* vNum, float* wNum, float* detOut)
+{
+    const float a0 = p0.x - r.ox, a1 = p0.y - r.oy, a2 = p0.z - r.oz;
+    const float b0 = p1.x - r.ox, b1 = p1.y - r.oy, b2 = p1.z - r.oz;
+    const float c0 = p2.x - r.ox, c1 = p2.y - r.oy, c2 = p2.z - r.oz;
+    const float akx = sel3(a0, a1, a2, r.kx), aky = sel3(a0, a1, a2, r.ky), akz = sel3(a0, a1, a2, r.kz);
+    const float bkx = sel3(b0, b1, b2, r.kx), bky = sel3(b0, b1, b2, r.ky), bkz = sel3(b0, b1, b2, r.kz);
+    const float ckx = sel3(c0, c1, c2, r.kx), cky = sel3(c0, c1, c2, r.ky), ckz = sel3(c0, c1, c2, r.kz);
+    const float Ax = akx - r.Sx * akz, Ay = aky - r.Sy * akz;
+    const float Bx = bkx - r.Sx * bkz, By = bky - r.Sy * bkz;
+    const float Cx = ckx - r.Sx * ckz, Cy = cky - r.Sy * ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    {
+        const double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        const double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        const double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = U + V + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * akz, Bz = r.Sz * bkz, Cz = r.Sz * ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float t = T / det;
+    if (!(t > tNear && t <= tFar)) return false;
+    *tOut = t; *vNum = V; *wNum = W; *detOut = det;
     return true;
 }
 
