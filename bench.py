@@ -155,14 +155,14 @@ def main():
     if rank == 0:
         mean, stddev = trace.stddev()
         # roofline of the dominant kernel (the closest-hit traversal, 2 launches per bounce): algorithmic bytes
-        # per ray = 32 (ray) + 16 (hit) + 128 per BVH4 node fetched (= 2 BVH2-equivalent nodes of 64 B) + 48 per
+        # per ray = 32 (ray) + 16 (hit) + 64 per BVH4 node fetched (the 64-byte compressed node) + 48 per
         # triangle tested, with the per-ray node / triangle counts MEASURED by the counting build of the kernel
         # on one more frame of the same workload (outside the timed region)
         api.work_counters(True)
         step(args.steps)
         nodes, tris, crays, worst = api.work_counters(False)
         crays = max(crays, 1)
-        b_ray = 48.0 + 128.0 * nodes / crays + 48.0 * tris / crays
+        b_ray = 48.0 + 64.0 * nodes / crays + 48.0 * tris / crays
         achieved = rays * b_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         # HBM-side bytes per traversal launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
         # rocprofv3 runs of this same command: scripts/profile_bench.sh -> profiles/traffic.json); counters cannot

@@ -350,9 +350,11 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         atomicAdd(&a.stats[0], (unsigned long long)count);   /* extension rays of this bounce */
     }
     uint32_t shadow = 0, other = 0; bool overflow = false;
-    for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    /* SLOW: the short list is dealt round-robin over the blocks (entry e -> block e % grid), so that its few hundred
+     * heavy paths run on every CU at once, a few lanes per wave, instead of filling the waves of two blocks */
+    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t idx = base + threadIdx.x;
+        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;
         bool deferred = false;
         int32_t pos = 0;
         if (idx < count)
@@ -510,9 +512,9 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
     if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
     __shared__ int32_t sh[2 + kShadeThreads / 64];
     uint32_t other = 0; bool overflow = false;
-    for (int32_t base = blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t idx = base + threadIdx.x;
+        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;   /* as in shade_a */
         bool alive = false, deferred = false;
         int32_t slot = 0, pos = 0;
         v4 ro = f4_s(0.0f), rd = f4_s(0.0f);

@@ -38,7 +38,7 @@ if mode == "rays":
     for _ in range(reps): run()
     dt = (time.perf_counter() - t0) / reps
     api.work_counters(True); run(); nodes, tris, rays, worst = api.work_counters(False)
-    b_ray = 48.0 + 128.0 * nodes / rays + 48.0 * tris / rays
+    b_ray = 48.0 + 64.0 * nodes / rays + 48.0 * tris / rays
     emit({"what": "incoherent closest-hit microbenchmark", "scene_tris": info.triCount, "rays_per_launch": nray, "ms_per_launch": dt * 1e3,
           "Mrays_per_s": nray / dt / 1e6, "nodes_per_ray": nodes / rays, "tris_per_ray": tris / rays, "max_nodes_one_ray": worst,
           "bytes_per_ray": b_ray, "algorithmic_GBps": nray * b_ray / dt / 1e9, "frac_of_8TBps": nray * b_ray / dt / 8e12,
