@@ -27,7 +27,9 @@
 
 namespace pt {
 
+#ifndef PT_STACK_LDS
 #define PT_STACK_LDS    12
+#endif
 #define PT_STACK_SPILL  52
 #define PT_STACK_MAX    (PT_STACK_LDS + PT_STACK_SPILL)
 
