@@ -119,7 +119,7 @@ def main():
         p.sampleIndex = pdist.sample_indices(rank, world, i + 1)[i]
         trace.trace(scene, cam, dof, p)
         s = trace.stats()
-        return s.extensionRays + s.shadowRays + s.otherRays, s.traceMs, s.totalMs
+        return s.extensionRays + s.shadowRays + s.otherRays, s.traceMs, s.totalMs, s.tailRays, 2 * s.bounces
 
     def sync():
         if world > 1:
@@ -133,11 +133,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     rays = 0
+    tail_rays = 0        # traced inside the tail kernel (deep bounces), not by the k_trace launches that trace_ms covers
+    launches = 0
     trace_ms = 0.0
     total_ms = 0.0
     for i in range(args.steps):
-        r, tm, tot = step(i)
-        rays += r; trace_ms += tm; total_ms += tot
+        r, tm, tot, tr, nl = step(i)
+        rays += r; trace_ms += tm; total_ms += tot; tail_rays += tr; launches += nl
     if world > 1:
         # the path's one exchange step: sum of the per-GPU mean images on rank 0 (RCCL reduce over xGMI)
         trace.copy_dev(reduce_buf.data_ptr())
@@ -163,7 +165,9 @@ def main():
         nodes, tris, crays, worst = api.work_counters(False)
         crays = max(crays, 1)
         b_ray = 48.0 + 64.0 * nodes / crays + 48.0 * tris / crays
-        achieved = rays * b_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        batched = rays - tail_rays          # rays of the k_trace launches
+        launches = max(launches, 1)
+        achieved = batched * b_ray / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         # HBM-side bytes per traversal launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
         # rocprofv3 runs of this same command: scripts/profile_bench.sh -> profiles/traffic.json); counters cannot
         # be read inside this process, so the figure is the committed measurement of this workload, or null
@@ -186,10 +190,10 @@ def main():
             "device_ms_per_step": total_ms / args.steps, "traversal_ms_per_step": trace_ms / args.steps,
             "roofline": {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": rays / (args.steps * 2 * wl["bounces"]) * b_ray,
+                         "bytes_per_launch": batched / launches * b_ray,
                          "bytes_per_ray": b_ray, "nodes_per_ray": nodes / crays, "tris_per_ray": tris / crays, "max_nodes_one_ray": worst,
-                         "rays_per_launch": rays / (args.steps * 2 * wl["bounces"]),
-                         "avg_launch_ms": trace_ms / (args.steps * 2 * wl["bounces"])},
+                         "rays_per_launch": batched / launches, "launches_per_step": launches / args.steps,
+                         "avg_launch_ms": trace_ms / launches, "tail_kernel_rays_per_step": tail_rays / args.steps},
         }
         if not args.no_cpu_baseline and world == 1:
             threads = min(16, os.cpu_count() or 1)

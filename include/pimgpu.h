@@ -337,9 +337,11 @@ typedef struct PimTraceStats
     uint64_t shadowRays;
     uint64_t otherRays;         /* media NEE + refraction thickness + autofocus */
     uint64_t paths;
-    int32_t  bounces;           /* bounce iterations launched */
+    int32_t  bounces;           /* wavefront bounce iterations launched (two traversal launches each) before the tail kernel */
     float    traceMs;           /* device time inside the traversal kernels */
     float    totalMs;           /* device time of the whole call */
+    uint64_t tailRays;          /* of the rays above: traced inside the tail kernel, which finishes the short queues of deep
+                                   bounces in one launch (not by the batched traversal launches traceMs covers) */
 } PimTraceStats;
 int pimgpu_trace_stats(const PimTrace* trace, PimTraceStats* out);
 

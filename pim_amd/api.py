@@ -73,7 +73,8 @@ class PimTraceParams(C.Structure):
 
 class PimTraceStats(C.Structure):
     _fields_ = [("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("otherRays", C.c_uint64),
-                ("paths", C.c_uint64), ("bounces", C.c_int32), ("traceMs", C.c_float), ("totalMs", C.c_float)]
+                ("paths", C.c_uint64), ("bounces", C.c_int32), ("traceMs", C.c_float), ("totalMs", C.c_float),
+                ("tailRays", C.c_uint64)]
 
 
 class PimMesh(C.Structure):

@@ -44,6 +44,11 @@ static constexpr int kShadeThreads = 512;
 #define PT_NEE_MEDIA  3     /* the medium scattered the path: bounce already applied */
 #define PT_NEE_DEAD   4     /* path finished in shade_a */
 
+/* counters[]: [0],[1] queue lengths, [2],[3] slow-list lengths, [PT_COUNTS_BASE + b] queue length at the start of bounce b
+ * (read back with the statistics: the host's tail policy of the next call) */
+#define PT_COUNTS_BASE 8
+#define PT_COUNTS_MAX  56
+
 void WorkBuffers::release()
 {
     hipFree(rayO); hipFree(rayD);
@@ -115,7 +120,7 @@ struct StageArgs
     const int32_t* queueIn; int32_t* queueOut;
     int32_t* counters;              /* [0], [1]: lengths of queue[0], queue[1] */
     int32_t inSel;                  /* which queue is the input of this bounce */
-    const float4* extD;             /* unused by the stages (rd is path state) */
+    const float4* extO; const float4* extD;   /* extension rays of the input queue, by position (the tail kernel starts from them) */
     const DHit* extHit; const DHit* neeHit;
     float4* neeO; float4* neeD;
     float4* extOOut; float4* extDOut;
@@ -339,28 +344,15 @@ __global__ __launch_bounds__(64) void k_ambcube_fit(const PimResult* __restrict_
 /* ---------------------------------------------------------------------------------------------- */
 /* shade_a: everything of a bounce between the extension hit and the direct-light ray              */
 
+/* one path through the stage: its state is read from and written back to the path-state arrays (slot); the direct-light
+ * ray comes back in the result (tFar < tNear: none).  `deferred` (FAST build only): nothing was written, the SLOW build
+ * redoes the stage. */
+struct StageAOut { float4 nO, nD; bool deferred; uint32_t shadow, other; bool overflow; };
+
 template <bool SLOW>
-__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_a(DScene s, StageArgs a)
+__device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a, int32_t slot, const DHit extHit, int32_t bounce)
 {
-    const int32_t count = SLOW ? a.counters[2] : a.counters[a.inSel];
-    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        a.counters[a.inSel ^ 1] = 0;                         /* output queue of shade_b starts empty */
-        a.counters[3] = 0;                                   /* and so does shade_b's slow list */
-        atomicAdd(&a.stats[0], (unsigned long long)count);   /* extension rays of this bounce */
-    }
-    uint32_t shadow = 0, other = 0; bool overflow = false;
-    /* SLOW: the short list is dealt round-robin over the blocks (entry e -> block e % grid), so that its few hundred
-     * heavy paths run on every CU at once, a few lanes per wave, instead of filling the waves of two blocks */
-    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
-    {
-        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;
-        bool deferred = false;
-        int32_t pos = 0;
-        if (idx < count)
-        {
-        pos = SLOW ? a.slowA[idx] : idx;
-        const int32_t slot = a.queueIn[pos];
+        StageAOut out; out.deferred = false; out.shadow = 0; out.other = 0; out.overflow = false;
         Ctx ctx = ctx_make();
         { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
         const v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
@@ -374,7 +366,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         float4 nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nD = make_float4(0.0f, 0.0f, 1.0f, -1.0f);   /* tFar < tNear: no ray */
         bool finished = false;
 
-        const RayHit hit = make_rayhit(s, rd, a.extHit[pos]);
+        const RayHit hit = make_rayhit(s, rd, extHit);
         if (hit.type == PIM_HIT_NOTHING)
         {
             luminance = f4_add(luminance, f4_mul(attenuation, GetSky(s, rd)));        /* pt.c:2334-2338 */
@@ -414,8 +406,8 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
             {
                 attenuation = f4_mul(attenuation, ms.attenuation);
                 const SurfHit surf = GetSurface(s, rd, hit);                          /* pt.c:2369 */
-                if (a.bounce > 0) LightOnHit(s, ro, surf.emission, hit.iVert);        /* pt.c:2370-2373 */
-                if ((a.bounce == 0) || (prevFlags & PIM_MATFLAG_REFRACTIVE))
+                if (bounce > 0) LightOnHit(s, ro, surf.emission, hit.iVert);        /* pt.c:2370-2373 */
+                if ((bounce == 0) || (prevFlags & PIM_MATFLAG_REFRACTIVE))
                 {
                     const float keep = luminance.w;
                     luminance = f4_add(luminance, f4_mul(surf.emission, attenuation)); /* pt.c:2375-2378 */
@@ -444,7 +436,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                                     nee0 = make_float4(__int_as_float(PT_NEE_LIGHT), __int_as_float(iVert), selectPdf, lr.distSq);
                                     nO = make_float4(surf.P.x, surf.P.y, surf.P.z, 0.0f);
                                     nD = make_float4(lr.rd.x, lr.rd.y, lr.rd.z, lr.distance + 0.01f * PT_MILLI);
-                                    ++shadow;
+                                    ++out.shadow;
                                 }
                             }
                         }
@@ -458,18 +450,17 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                                 nee1 = make_float4(sample.attenuation.x, sample.attenuation.y, sample.attenuation.z, sample.pdf);
                                 nO = make_float4(surf.P.x, surf.P.y, surf.P.z, 0.0f);
                                 nD = make_float4(sample.dir.x, sample.dir.y, sample.dir.z, PT_RCP_EPS);
-                                ++shadow;
+                                ++out.shadow;
                             }
                         }
                     }
                 }
             }
         }
-        deferred = !SLOW && ctx.defer;
-        if (deferred)
+        out.deferred = !SLOW && ctx.defer;
+        if (out.deferred)
         {
             /* park the lane's NEE slot (no ray) and leave the state as it was */
-            a.neeO[pos] = nO; a.neeD[pos] = nD;
         }
         else
         {
@@ -485,9 +476,38 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
             a.ps.lum[slot] = make_float4(luminance.x, luminance.y, luminance.z, luminance.w);
         }
         a.ps.nee0[slot] = nee0; a.ps.nee1[slot] = nee1;
-        a.neeO[pos] = nO; a.neeD[pos] = nD;
-        other += ctx.otherRays; overflow |= ctx.overflow;
+        out.other = ctx.otherRays; out.overflow = ctx.overflow;
         }
+        out.nO = nO; out.nD = nD;
+        return out;
+}
+
+template <bool SLOW>
+__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_a(DScene s, StageArgs a)
+{
+    const int32_t count = SLOW ? a.counters[2] : a.counters[a.inSel];
+    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        a.counters[a.inSel ^ 1] = 0;                         /* output queue of shade_b starts empty */
+        a.counters[3] = 0;                                   /* and so does shade_b's slow list */
+        a.counters[PT_COUNTS_BASE + min(a.bounce, PT_COUNTS_MAX - 1)] = count;   /* history for the host's tail policy */
+        atomicAdd(&a.stats[0], (unsigned long long)count);   /* extension rays of this bounce */
+    }
+    uint32_t shadow = 0, other = 0; bool overflow = false;
+    /* SLOW: the short list is dealt round-robin over the blocks (entry e -> block e % grid), so that its few hundred
+     * heavy paths run on every CU at once, a few lanes per wave, instead of filling the waves of two blocks */
+    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    {
+        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;
+        bool deferred = false;
+        int32_t pos = 0;
+        if (idx < count)
+        {
+            pos = SLOW ? a.slowA[idx] : idx;
+            const StageAOut r = stage_a<SLOW>(s, a, a.queueIn[pos], a.extHit[pos], a.bounce);
+            a.neeO[pos] = r.nO; a.neeD[pos] = r.nD;
+            deferred = r.deferred;
+            shadow += r.shadow; other += r.other; overflow |= r.overflow;
         }
         if (!SLOW)
         {
@@ -504,31 +524,21 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
 /* ---------------------------------------------------------------------------------------------- */
 /* shade_b: from the direct-light hit to the next extension ray                                    */
 
+/* one path through the stage; `alive`: the path goes on with the extension ray (ro, rd) */
+struct StageBOut { bool alive, deferred; v4 ro, rd; uint32_t other; bool overflow; };
+
 template <bool SLOW>
-__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_b(DScene s, StageArgs a)
+__device__ __forceinline__ StageBOut stage_b(const DScene& s, const StageArgs& a, int32_t slot, const DHit extHit, const float4 neeD,
+    const DHit neeHit, int32_t bounce)
 {
-    const int32_t count = SLOW ? a.counters[3] : a.counters[a.inSel];
-    int32_t* countOut = &a.counters[a.inSel ^ 1];
-    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
-    __shared__ int32_t sh[2 + kShadeThreads / 64];
-    uint32_t other = 0; bool overflow = false;
-    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
-    {
-        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;   /* as in shade_a */
-        bool alive = false, deferred = false;
-        int32_t slot = 0, pos = 0;
-        v4 ro = f4_s(0.0f), rd = f4_s(0.0f);
-        if (idx < count)
-        {
-            pos = SLOW ? a.slowB[idx] : idx;
-            slot = a.queueIn[pos];
+            StageBOut out; out.alive = false; out.deferred = false; out.ro = f4_s(0.0f); out.rd = f4_s(0.0f); out.other = 0; out.overflow = false;
             const float4 nee0 = a.ps.nee0[slot];
             const int32_t mode = __float_as_int(nee0.x);
             if (mode != PT_NEE_DEAD)
             {
                 Ctx ctx = ctx_make();
                 { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
-                ro = ld4(a.ps.ro, slot); rd = ld4(a.ps.rd, slot);
+                v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
                 v4 attenuation = ld4(a.ps.atten, slot);
                 float resultWeight = attenuation.w;
                 v4 luminance = ld4(a.ps.lum, slot);
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                 bool finished = false;
                 if (mode != PT_NEE_MEDIA)
                 {
-                    const RayHit hit = make_rayhit(s, rd, a.extHit[pos]);
+                    const RayHit hit = make_rayhit(s, rd, extHit);
                     const SurfHit surf = GetSurface(s, rd, hit);
                     /* EstimateDirect after its ray, pt.c:1871-1897 / 1907-1918 */
                     v4 Li = f4_s(0.0f);
@@ -545,9 +555,9 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                     {
                         const float pRough = f1_lerp(0.05f, 0.95f, surf.roughness);
                         const float pSmooth = 1.0f - pRough;
-                        const float4 nD = a.neeD[pos];
+                        const float4 nD = neeD;
                         const v4 nrd = f4_v(nD.x, nD.y, nD.z, 0.0f);
-                        const RayHit nh = make_rayhit(s, nrd, a.neeHit[pos]);
+                        const RayHit nh = make_rayhit(s, nrd, neeHit);
                         if (mode == PT_NEE_LIGHT)
                         {
                             const int32_t iVert = __float_as_int(nee0.y);
@@ -620,11 +630,11 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                 /* top of bounce b+1, pt.c:2319-2331 */
                 if (!finished)
                 {
-                    if (a.bounce + 1 >= a.bounceLimit) finished = true;
+                    if (bounce + 1 >= a.bounceLimit) finished = true;
                     else if (!roulette(ctx, attenuation)) finished = true;
                 }
-                deferred = !SLOW && ctx.defer;
-                if (deferred)
+                out.deferred = !SLOW && ctx.defer;
+                if (out.deferred)
                 {
                     /* refraction or a collision on the light ray: nothing written, the SLOW build redoes this stage */
                 }
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                 }
                 else
                 {
-                    alive = true;
+                    out.alive = true; out.ro = ro; out.rd = rd;
                     a.ps.rng[slot] = make_uint4(ctx.rng.x, ctx.rng.y, ctx.rng.z, ctx.rng.w);
                     a.ps.ro[slot] = make_float4(ro.x, ro.y, ro.z, 0.0f);
                     a.ps.rd[slot] = make_float4(rd.x, rd.y, rd.z, 0.0f);
@@ -642,8 +652,32 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
                     a.ps.lum[slot] = make_float4(luminance.x, luminance.y, luminance.z, __uint_as_float(prevFlags));
                     st4(a.ps.albedo, slot, albedoAcc); st4(a.ps.normal, slot, normalAcc);
                 }
-                if (!deferred) { other += ctx.otherRays; overflow |= ctx.overflow; }
+                if (!out.deferred) { out.other = ctx.otherRays; out.overflow = ctx.overflow; }
             }
+            return out;
+}
+
+template <bool SLOW>
+__global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_b(DScene s, StageArgs a)
+{
+    const int32_t count = SLOW ? a.counters[3] : a.counters[a.inSel];
+    int32_t* countOut = &a.counters[a.inSel ^ 1];
+    if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
+    __shared__ int32_t sh[2 + kShadeThreads / 64];
+    uint32_t other = 0; bool overflow = false;
+    for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
+    {
+        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;   /* as in shade_a */
+        bool alive = false, deferred = false;
+        int32_t slot = 0, pos = 0;
+        v4 ro = f4_s(0.0f), rd = f4_s(0.0f);
+        if (idx < count)
+        {
+            pos = SLOW ? a.slowB[idx] : idx;
+            slot = a.queueIn[pos];
+            const StageBOut r = stage_b<SLOW>(s, a, slot, a.extHit[pos], a.neeD[pos], a.neeHit[pos], a.bounce);
+            alive = r.alive; deferred = r.deferred; ro = r.ro; rd = r.rd;
+            other += r.other; overflow |= r.overflow;
         }
         /* russian-roulette compaction: survivors of this wave take consecutive queue positions */
         {
@@ -662,6 +696,52 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         }
     }
     block_add(&a.stats[2], other, sh);
+    if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* tail: every remaining bounce of a path in ONE launch                                            */
+
+/*
+ * Deep bounces hold few paths (russian roulette), and a wavefront bounce costs six dependent launches whatever its
+ * size: two traversal launches and four stage launches at their latency floors (about 170 us per bounce on Cornell
+ * 1080p for a queue that has shrunk to a few per cent of the image).  Once the queue is short the host hands it to this
+ * kernel instead: one lane per path runs the rest of Pt_TraceRay's loop (pt.c:2319-2407) to the end -- the same stage
+ * functions (SLOW builds: everything inline) and the inline closest-hit traversal.  Path state still goes through
+ * the path-state arrays exactly as between the wavefront's launches, and every path owns its Prng stream, so where
+ * the switch happens does not change a bit of the result (tested for every switch point).
+ */
+static constexpr int kTailThreads = 256;
+
+__global__ __launch_bounds__(kTailThreads, 1) void k_tail(DScene s, StageArgs a)
+{
+    const int32_t count = a.counters[a.inSel];
+    uint32_t ext = 0, shadow = 0, other = 0; bool overflow = false;
+    for (int32_t pos = blockIdx.x * kTailThreads + threadIdx.x; pos < count; pos += gridDim.x * kTailThreads)
+    {
+        const int32_t slot = a.queueIn[pos];
+        float4 o = a.extO[pos], d = a.extD[pos];
+        for (int32_t b = a.bounce; ; ++b)
+        {
+            TrivialStack st;
+            const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
+            ++ext;
+            const StageAOut ra = stage_a<true>(s, a, slot, eh, b);
+            shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
+            DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
+            if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
+            const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b);
+            other += rb.other; overflow |= rb.overflow;
+            if (!rb.alive) break;
+            o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
+            d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
+        }
+    }
+    __shared__ int32_t sh[2 + kTailThreads / 64];
+    block_add(&a.stats[0], ext, sh);
+    block_add(&a.stats[1], shadow, sh);
+    block_add(&a.stats[2], other, sh);
+    block_add(&a.stats[5], ext + shadow, sh);        /* rays traced here, not by the batched traversal launches */
     if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
 }
 
@@ -723,12 +803,30 @@ __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ ter
 /* ---------------------------------------------------------------------------------------------- */
 /* host: the bounce loop                                                                           */
 
+/*
+ * Where the wavefront hands over to the tail kernel.  The queue lengths are device-side; the host uses those of the
+ * PREVIOUS call (progressive rendering repeats the same camera and scene), read back with the statistics: the first
+ * bounce whose queue was shorter than 1/kTailFraction of the batch.  The choice only moves time around (k_tail's
+ * header), so a stale history is harmless; PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
+ */
+static constexpr int kTailFraction = 12;
+
+static int32_t tail_policy(const WorkBuffers& w, int32_t n, int32_t bounceLimit)
+{
+    if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
+    if (w.historyN != n || w.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
+    for (int32_t b = 1; b < w.historyBounces && b < bounceLimit; ++b)
+        if ((int64_t)w.history[b] * kTailFraction < n) return b;
+    return bounceLimit == 666 ? std::max(16, w.historyBounces) : bounceLimit;
+}
+
 int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
 {
     WorkBuffers& w = g_lib.work;
     hipStream_t st = g_lib.stream;
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
-    const int32_t init[4] = { n, 0, 0, 0 };
+    const int32_t tailBounce = tail_policy(w, n, bounceLimit);
+    int32_t init[64] = {}; init[0] = n;
     PT_HIP(hipMemcpyAsync(w.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(w.stats, 0, 64, st));
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
@@ -738,14 +836,24 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
     int rc = PIMGPU_OK;
+    int32_t wavefrontBounces = 0;
     for (int32_t b = 0; b < bounceLimit; ++b)
     {
         const int in = b & 1, out = in ^ 1;
         StageArgs a;
         a.ps = w.ps; a.queueIn = w.queue[in]; a.queueOut = w.queue[out]; a.counters = w.counters; a.inSel = in;
-        a.extD = w.extD[in]; a.extHit = w.extHit; a.neeHit = w.neeHit; a.neeO = w.neeO; a.neeD = w.neeD;
+        a.extO = w.extO[in]; a.extD = w.extD[in]; a.extHit = w.extHit; a.neeHit = w.neeHit; a.neeO = w.neeO; a.neeD = w.neeD;
         a.extOOut = w.extO[out]; a.extDOut = w.extD[out]; a.results = w.results; a.stats = w.stats;
         a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA; a.slowB = w.slowB;
+        if (b >= tailBounce)
+        {
+            /* the queue is short by now (or the caller forced it): one launch finishes every path */
+            const int tailBlocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * 4, ((int64_t)n + kTailThreads - 1) / kTailThreads);
+            k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
+            if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
+            break;
+        }
+        ++wavefrontBounces;
         if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
         if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[in], w.extD[in], w.extHit, n, w.counters + in, st))) break;
         if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
@@ -757,24 +865,25 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
         k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
-        /* roulette-only termination (maxBounces <= 0): look at the queue length now and then */
-        if (bounceLimit == 666 && b >= 7 && (b % 4) == 3)
-        {
-            int32_t c[2];
-            PT_HIP(hipMemcpyAsync(c, w.counters, sizeof(c), hipMemcpyDeviceToHost, st));
-            PT_HIP(hipStreamSynchronize(st));
-            if (c[out] == 0) break;
-        }
     }
     if (rc) return rc;
     unsigned long long hs[8];
+    int32_t counts[64];
     PT_HIP(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(counts, w.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
     for (auto& e : events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow"); return PIMGPU_E_LIMIT; }
+    /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
+     * what the history knew beyond its switch point. */
+    if (w.historyN != n) { w.historyN = n; w.historyBounces = 0; }
+    for (int32_t b = 0; b < wavefrontBounces && b < PT_COUNTS_MAX; ++b) w.history[b] = counts[PT_COUNTS_BASE + b];
+    w.historyBounces = std::max(w.historyBounces, std::min<int32_t>(wavefrontBounces, PT_COUNTS_MAX));
     if (statsOut)
     {
         statsOut->extensionRays += hs[0]; statsOut->shadowRays += hs[1]; statsOut->otherRays += hs[2];
+        statsOut->tailRays += hs[5];
+        statsOut->bounces += wavefrontBounces;
         statsOut->paths += (uint64_t)n;
     }
     if (traceMsOut) *traceMsOut = traceMs;
@@ -879,7 +988,6 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     hipEventDestroy(e0); hipEventDestroy(e1);
     stats.otherRays += otherRays;
     stats.traceMs = traceMs; stats.totalMs = totalMs;
-    stats.bounces = 0;
     t->stats = stats;
     return PIMGPU_OK;
 }

@@ -66,6 +66,8 @@ struct WorkBuffers
     int32_t* counters = nullptr;        /* [0],[1]: queue lengths; [2],[3]: slow-list lengths; device side */
     unsigned long long* stats = nullptr;/* ext, shadow, other rays */
     PimResult* results = nullptr;       /* per path slot */
+    /* queue length at the start of each wavefront bounce of the previous integrate call (host copy): the tail policy */
+    int32_t history[64] = {}; int32_t historyBounces = 0; int64_t historyN = -1;
     int ensure_rays(int64_t n);
     int ensure_paths(int64_t n);
     void release();

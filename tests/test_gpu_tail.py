@@ -1,0 +1,78 @@
+"""-m gpu: the tail kernel (pim_amd/csrc/integrate.hip k_tail), which finishes the short queues of deep bounces in one
+launch.  Where the wavefront hands over to it only moves time around: for EVERY switch point -- including bounce 0, the
+whole integrator as one launch -- colour / albedo / normal, ray counts, autofocus state, light histograms and
+pt_stddev equal the oracle's scalar Pt_TraceRay bit for bit (the checks of tests/test_gpu_image.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from pim_amd import api, scenes
+from tests.gpu_util import gpu_init
+from tests.test_gpu_image import _render_both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def tail_env():
+    old = os.environ.get("PIMGPU_TAIL_BOUNCE")
+    yield
+    if old is None:
+        os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
+    else:
+        os.environ["PIMGPU_TAIL_BOUNCE"] = old
+
+
+@pytest.mark.parametrize("switch", ["-1", "0", "1", "3", "7"])
+def test_cornell_every_switch_point_bit_exact(tail_env, switch):
+    os.environ["PIMGPU_TAIL_BOUNCE"] = switch
+    color = _render_both(scenes.cornell_box(), 128, 72, 3, 8)
+    assert np.isfinite(color).all() and color.mean() > 0.01
+
+
+@pytest.mark.parametrize("switch", ["0", "2"])
+def test_tail_refractive_sky_media_and_roulette_bit_exact(tail_env, switch):
+    """the heavy cases inside the tail: thickness rays of refractive spheres, sky misses, a dense medium with in-scatter
+    light rays, and the reference's roulette-only termination (no bounce clamp)"""
+    os.environ["PIMGPU_TAIL_BOUNCE"] = switch
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
+    _render_both(scenes.cornell_box(media=scenes.foggy_media(6.0)), 64, 36, 2, 5)
+    _render_both(scenes.cornell_box(), 80, 45, 2, 0)
+
+
+def test_tail_policy_uses_the_previous_call(tail_env):
+    """without the override the host switches where the previous call's queue fell below 1/12 of the batch: the first
+    call runs every bounce as a wavefront, later calls hand the deep bounces to the tail kernel -- same bits either way"""
+    os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
+    gpu_init()
+    sc = scenes.cornell_box()
+    g = api.Scene(sc.desc)
+    W, H = 160, 90
+    t = api.Trace(W, H)
+    dof = scenes.default_dof()
+    seen = []
+    for s in range(3):
+        t.trace(g, scenes.pt_test_camera(), dof, scenes.trace_params(s, seed=3, max_bounces=12))
+        st = t.stats()
+        seen.append((st.bounces, st.tailRays))
+    assert seen[0] == (12, 0)                          # no history: all wavefront
+    assert 1 <= seen[1][0] < 12 and seen[1][1] > 0     # history: short queues go to the tail kernel
+    assert seen[2][0] == seen[1][0]
+    a = t.download()[0]
+    os.environ["PIMGPU_TAIL_BOUNCE"] = "-1"
+    g2 = api.Scene(sc.desc)                             # a fresh scene: the light histograms adapt from frame to frame
+    t2 = api.Trace(W, H)
+    dof2 = scenes.default_dof()
+    for s in range(3):
+        t2.trace(g2, scenes.pt_test_camera(), dof2, scenes.trace_params(s, seed=3, max_bounces=12))
+        assert t2.stats().tailRays == 0
+    assert (t2.download()[0].view(np.uint32) == a.view(np.uint32)).all()
+    t.close(); t2.close(); g.close(); g2.close()
+
+
+def test_lightmap_bake_through_the_tail_bit_exact(tail_env):
+    from tests.test_gpu_lightmap import test_cornell_bake_bit_exact
+    os.environ["PIMGPU_TAIL_BOUNCE"] = "1"
+    test_cornell_bake_bit_exact()
