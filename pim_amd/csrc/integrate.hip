@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
  * the path-state arrays exactly as between the wavefront's launches, and every path owns its Prng stream, so where
  * the switch happens does not change a bit of the result (tested for every switch point).
  */
-static constexpr int kTailThreads = 256;
+static constexpr int kTailThreads = 64;       /* one wave per block: the scheduler balances the uneven paths wave by wave */
 
 __global__ __launch_bounds__(kTailThreads, 1) void k_tail(DScene s, StageArgs a)
 {
@@ -848,7 +848,11 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
         if (b >= tailBounce)
         {
             /* the queue is short by now (or the caller forced it): one launch finishes every path */
-            const int tailBlocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * 4, ((int64_t)n + kTailThreads - 1) / kTailThreads);
+            /* one lane per path of the expected queue (the previous call's length at this bounce, + 25 %); the kernel strides
+             * over whatever the queue really holds */
+            const int64_t expect = (w.historyN == n && b < w.historyBounces) ? (int64_t)w.history[b] + w.history[b] / 4 : (int64_t)n;
+            const int64_t want = std::max<int64_t>((int64_t)g_lib.cuCount * 8, (expect + kTailThreads - 1) / kTailThreads);
+            const int tailBlocks = (int)std::min<int64_t>(want, ((int64_t)n + kTailThreads - 1) / kTailThreads);
             k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
