@@ -39,4 +39,5 @@ for kind in ("uniform", "surface"):
         api.work_counters(True); run(n); nodes, tris, rays, worst = api.work_counters(False)
         print(f"{kind:8s} n={n:8d} {n / dt / 1e6:8.1f} Mrays/s  {dt * 1e3:7.3f} ms  nodes/ray {nodes / max(rays, 1):6.1f} tris/ray {tris / max(rays, 1):6.1f} worst ray {worst} nodes", flush=True)
     h = hits.cpu().numpy()
-    print("   hit fraction", (h[:, 0] >= 0).mean())
+    # a checksum of the records: every build variant of the kernel must print the same line (the result does not depend on the tree walk)
+    print("   hit fraction", (h[:, 0] >= 0).mean(), "checksum", hex(int(np.bitwise_xor.reduce(h.view(np.uint32).astype(np.uint64).sum(axis=1) & 0xffffffff))))

@@ -5,5 +5,5 @@ set -e
 for lib in "$@"; do
   name=${lib:+_$lib}
   echo "== libpimgpu$name"
-  PIMGPU_LIB=$PWD/pim_amd/libpimgpu$name.so timeout -k 10 150 python -u scripts/raybench.py 1000000 4194304 2>/dev/null | grep "n= 4194304"
+  PIMGPU_LIB=$PWD/pim_amd/libpimgpu$name.so timeout -k 10 150 python -u scripts/raybench.py 1000000 4194304 2>/dev/null | grep "n= 4194304\|checksum"
 done
