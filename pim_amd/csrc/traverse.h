@@ -287,34 +287,37 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
     DHit h; h.prim = -1; h.t = tFar; h.u = 0.0f; h.v = 0.0f;
     if (!(tFar > tNear)) return h;
     const RayPre r = ray_pre(ox, oy, oz, dx, dy, dz);
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     st.init();
     int32_t cur = 0;
-    const float4* __restrict__ nodes = bvh.nodes;
-    const RayPad pad = ray_pad(ox, oy, oz, nodes[7].x);
+    const uint4* __restrict__ cnodes = bvh.cnodes;
+    const RaySlabQ sl = ray_slab_q(ox, oy, oz, dx, dy, dz, bvh.nodes[7].x);
+    const bool px = sl.ix >= 0.0f, py = sl.iy >= 0.0f, pz = sl.iz >= 0.0f;
     const float4* __restrict__ tris = bvh.tris;
     for (;;)
     {
         if (cur >= 0)
         {
             if (COUNT) counts->nodes++;
-            const float4* q = nodes + (size_t)cur * 8;
-            const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-            const float4 ch = q[6];
+            /* the 64-byte compressed node (pt_device.h), decoded as in the batched kernel (trace.hip) */
+            const uint4* q = cnodes + (size_t)cur * 4;
+            const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
             float d[4]; int32_t c[4];
-            c[0] = __float_as_int(ch.x); c[1] = __float_as_int(ch.y); c[2] = __float_as_int(ch.z); c[3] = __float_as_int(ch.w);
-            const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
-            const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+            c[0] = (int32_t)w3.x; c[1] = (int32_t)w3.y; c[2] = (int32_t)w3.z; c[3] = (int32_t)w3.w;
+            const float ax = __uint_as_float(w0.w) * sl.ix, ay = __uint_as_float(w2.z) * sl.iy, az = __uint_as_float(w2.w) * sl.iz;
+            const float bnx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.nx), bfx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.fx);
+            const float bny = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.ny), bfy = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.fy);
+            const float bnz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.nz), bfz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.fz);
+            const uint32_t qnx = px ? w1.x : w1.w, qfx = px ? w1.w : w1.x;
+            const uint32_t qny = py ? w1.y : w2.x, qfy = py ? w2.x : w1.y;
+            const uint32_t qnz = pz ? w1.z : w2.y, qfz = pz ? w2.y : w1.z;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
             {
-                const float ax = (lx[k] - pad.xp) * ix, bx = (hx[k] - pad.xm) * ix;
-                const float ay = (ly[k] - pad.yp) * iy, by = (hy[k] - pad.ym) * iy;
-                const float az = (lz[k] - pad.zp) * iz, bz = (hz[k] - pad.zm) * iz;
-                float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tNear));
-                float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000004f;   /* conservative slab (Ize 2013) */
-                t1 = fminf(t1, h.t);
-                /* empty slots carry an inverted box, which the min/max slab test would read as infinite: test the tag */
+                const float tnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 255u), ax, bnx), tfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 255u), ax, bfx);
+                const float tny = __builtin_fmaf((float)((qny >> (8 * k)) & 255u), ay, bny), tfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 255u), ay, bfy);
+                const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 255u), az, bnz), tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 255u), az, bfz);
+                const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tNear));
+                const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, h.t));
                 d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
             }
             /* sort the 4 candidates by entry distance (5-comparator network); misses carry +inf */
