@@ -156,6 +156,7 @@ int pimgpu_shutdown(void)
 {
     if (!g_lib.initialised) return PIMGPU_OK;
     hipStreamSynchronize(g_lib.stream);
+    g_lib.release_groups();
     g_lib.work.release();
     g_lib.trace.release();
     hipStreamDestroy(g_lib.stream);

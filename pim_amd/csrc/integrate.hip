@@ -128,6 +128,7 @@ struct StageArgs
     unsigned long long* stats;
     int32_t bounce, bounceLimit;
     int32_t* slowA; int32_t* slowB; /* queue positions the FAST builds deferred (lengths: counters[2], counters[3]) */
+    int32_t tailLanes;              /* k_tail: lanes of each wave that take paths */
 };
 
 __device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
@@ -711,31 +712,46 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
  * the path-state arrays exactly as between the wavefront's launches, and every path owns its Prng stream, so where
  * the switch happens does not change a bit of the result (tested for every switch point).
  */
+#ifndef PT_TAIL_OCC
+#define PT_TAIL_OCC 1                          /* waves per SIMD the register budget is sized for */
+#endif
 static constexpr int kTailThreads = 64;       /* one wave per block: the scheduler balances the uneven paths wave by wave */
 
-__global__ __launch_bounds__(kTailThreads, 1) void k_tail(DScene s, StageArgs a)
+/*
+ * Paths die at different bounces, so a lane whose path has ended takes the next queued path at the top of the bounce
+ * loop (one wave-aggregated atomic on counters[4], zeroed by the host with the other counters) instead of idling until
+ * the longest path of its wave ends.  The host launches no more waves than the machine holds at this kernel's
+ * occupancy; every lane leaves once the cursor has passed the queue's end, so the grid drains.
+ */
+__global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, StageArgs a)
 {
     const int32_t count = a.counters[a.inSel];
     uint32_t ext = 0, shadow = 0, other = 0; bool overflow = false;
-    for (int32_t pos = blockIdx.x * kTailThreads + threadIdx.x; pos < count; pos += gridDim.x * kTailThreads)
+    bool have = false;
+    int32_t slot = 0, b = 0;
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o;
+    for (;;)
     {
-        const int32_t slot = a.queueIn[pos];
-        float4 o = a.extO[pos], d = a.extD[pos];
-        for (int32_t b = a.bounce; ; ++b)
+        if ((int32_t)(threadIdx.x & 63) >= a.tailLanes) break;
+        const int32_t pos = wave_append(&a.counters[4], !have);
+        if (!have)
         {
-            TrivialStack st;
-            const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
-            ++ext;
-            const StageAOut ra = stage_a<true>(s, a, slot, eh, b);
-            shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
-            DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
-            if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
-            const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b);
-            other += rb.other; overflow |= rb.overflow;
-            if (!rb.alive) break;
-            o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
-            d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
+            if (pos >= count) break;
+            slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true;
         }
+        TrivialStack st;
+        const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
+        ++ext;
+        const StageAOut ra = stage_a<true>(s, a, slot, eh, b);
+        shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
+        DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
+        if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
+        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b);
+        other += rb.other; overflow |= rb.overflow;
+        have = rb.alive;
+        o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
+        d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
+        ++b;
     }
     __shared__ int32_t sh[2 + kTailThreads / 64];
     block_add(&a.stats[0], ext, sh);
@@ -809,89 +825,201 @@ __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ ter
  * bounce whose queue was shorter than 1/kTailFraction of the batch.  The choice only moves time around (k_tail's
  * header), so a stale history is harmless; PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
  */
-static constexpr int kTailFraction = 12;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 12));      /* tuning knobs, not API */
+static const int kTailWavesPerCu = std::max(1, env_int("PIMGPU_TAIL_WAVES", 8));
 
-static int32_t tail_policy(const WorkBuffers& w, int32_t n, int32_t bounceLimit)
+static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
     if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
-    if (w.historyN != n || w.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
-    for (int32_t b = 1; b < w.historyBounces && b < bounceLimit; ++b)
-        if ((int64_t)w.history[b] * kTailFraction < n) return b;
-    return bounceLimit == 666 ? std::max(16, w.historyBounces) : bounceLimit;
+    if (g.historyN != n || g.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
+    for (int32_t b = 1; b < g.historyBounces && b < bounceLimit; ++b)
+        if ((int64_t)g.history[b] * kTailFraction < n) return b;
+    return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;
 }
 
-int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
+int Library::ensure_group(int gi)
+{
+    PathGroup& g = groups[gi];
+    if (gi == 0) { g.counters = work.counters; g.stats = work.stats; g.trace = &trace; }     /* the library's own, may have been reallocated */
+    if (g.stream) return PIMGPU_OK;
+    if (gi == 0) g.stream = stream;
+    else
+    {
+        PT_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+        PT_HIP(hipMalloc(&g.counters, 256));
+        PT_HIP(hipMalloc(&g.stats, 256));
+        int rc = g.ownTrace.ensure(); if (rc) return rc;
+        g.trace = &g.ownTrace;
+    }
+    PT_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    PT_HIP(hipEventCreateWithFlags(&g.stagger, hipEventDisableTiming));
+    return PIMGPU_OK;
+}
+
+void Library::release_groups()
+{
+    for (int gi = 0; gi < kMaxGroups; ++gi)
+    {
+        PathGroup& g = groups[gi];
+        if (!g.stream) continue;
+        if (g.done) hipEventDestroy(g.done);
+        if (g.stagger) hipEventDestroy(g.stagger);
+        if (gi > 0) { hipStreamSynchronize(g.stream); hipStreamDestroy(g.stream); hipFree(g.counters); hipFree(g.stats); g.ownTrace.release(); }
+        g = PathGroup();
+    }
+}
+
+/*
+ * Enqueue every bounce of the paths at queue positions [first, first + n) of the work buffers (slots are global, the
+ * position-indexed arrays are viewed from `first`) on the group's stream; nothing here waits for the device.
+ * staggerAfter >= 0: record g.stagger once that many half-bounces (traversal + stage) have been enqueued.
+ */
+static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32_t n, int32_t maxBounces, bool timeTrace, int staggerAfter)
 {
     WorkBuffers& w = g_lib.work;
-    hipStream_t st = g_lib.stream;
+    hipStream_t st = g.stream;
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
-    const int32_t tailBounce = tail_policy(w, n, bounceLimit);
+    const int32_t tailBounce = tail_policy(g, n, bounceLimit);
+    g.first = first; g.n = n; g.wavefrontBounces = 0; g.events.clear();
     int32_t init[64] = {}; init[0] = n;
-    PT_HIP(hipMemcpyAsync(w.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemsetAsync(w.stats, 0, 64, st));
+    PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(g.stats, 0, 64, st));
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    float traceMs = 0.0f;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
     int rc = PIMGPU_OK;
-    int32_t wavefrontBounces = 0;
+    int halves = 0;
+    bool staggered = staggerAfter < 0;
+    auto half_done = [&]() { if (!staggered && ++halves >= staggerAfter) { hipEventRecord(g.stagger, st); staggered = true; } };
+    if (!staggered && staggerAfter == 0) { hipEventRecord(g.stagger, st); staggered = true; }
     for (int32_t b = 0; b < bounceLimit; ++b)
     {
         const int in = b & 1, out = in ^ 1;
         StageArgs a;
-        a.ps = w.ps; a.queueIn = w.queue[in]; a.queueOut = w.queue[out]; a.counters = w.counters; a.inSel = in;
-        a.extO = w.extO[in]; a.extD = w.extD[in]; a.extHit = w.extHit; a.neeHit = w.neeHit; a.neeO = w.neeO; a.neeD = w.neeD;
-        a.extOOut = w.extO[out]; a.extDOut = w.extD[out]; a.results = w.results; a.stats = w.stats;
-        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA; a.slowB = w.slowB;
+        a.ps = w.ps; a.queueIn = w.queue[in] + first; a.queueOut = w.queue[out] + first; a.counters = g.counters; a.inSel = in;
+        a.extO = w.extO[in] + first; a.extD = w.extD[in] + first; a.extHit = w.extHit + first; a.neeHit = w.neeHit + first;
+        a.neeO = w.neeO + first; a.neeD = w.neeD + first;
+        a.extOOut = w.extO[out] + first; a.extDOut = w.extD[out] + first; a.results = w.results; a.stats = g.stats;
+        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64;
         if (b >= tailBounce)
         {
-            /* the queue is short by now (or the caller forced it): one launch finishes every path */
-            /* one lane per path of the expected queue (the previous call's length at this bounce, + 25 %); the kernel strides
-             * over whatever the queue really holds */
-            const int64_t expect = (w.historyN == n && b < w.historyBounces) ? (int64_t)w.history[b] + w.history[b] / 4 : (int64_t)n;
-            const int64_t want = std::max<int64_t>((int64_t)g_lib.cuCount * 8, (expect + kTailThreads - 1) / kTailThreads);
-            const int tailBlocks = (int)std::min<int64_t>(want, ((int64_t)n + kTailThreads - 1) / kTailThreads);
+            /* the queue is short by now (or the caller forced it): one launch finishes every path.
+             * One lane per path of the expected queue (the previous call's length at this bounce), but no more waves than
+             * the machine holds at k_tail's occupancy (2 per SIMD): lanes take further paths as theirs end */
+            const int64_t expect = (g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n;
+            a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
+            const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * kTailWavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
+            const int tailBlocks = (int)std::max<int64_t>(1, want);
             k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
         }
-        ++wavefrontBounces;
+        ++g.wavefrontBounces;
         if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
-        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[in], w.extD[in], w.extHit, n, w.counters + in, st))) break;
-        if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
+        if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st))) break;
+        if (timeTrace) { hipEventRecord(t1, st); g.events.push_back({ t0, t1 }); }
         k_shade_a<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_a<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
+        half_done();
         if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
-        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.neeO, w.neeD, w.neeHit, n, w.counters + in, st))) break;
-        if (timeTrace) { hipEventRecord(t1, st); events.push_back({ t0, t1 }); }
+        if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st))) break;
+        if (timeTrace) { hipEventRecord(t1, st); g.events.push_back({ t0, t1 }); }
         k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
+        half_done();
         if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
     }
-    if (rc) return rc;
+    if (!staggered) hipEventRecord(g.stagger, st);
+    return rc;
+}
+
+/* wait for the group's paths; statistics, the traversal time and the queue-length history of the next call's tail policy */
+static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceMsOut)
+{
+    hipStream_t st = g.stream;
     unsigned long long hs[8];
     int32_t counts[64];
-    PT_HIP(hipMemcpyAsync(hs, w.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
-    PT_HIP(hipMemcpyAsync(counts, w.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(hs, g.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(counts, g.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
-    for (auto& e : events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    float traceMs = 0.0f;
+    for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    g.events.clear();
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow"); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
      * what the history knew beyond its switch point. */
-    if (w.historyN != n) { w.historyN = n; w.historyBounces = 0; }
-    for (int32_t b = 0; b < wavefrontBounces && b < PT_COUNTS_MAX; ++b) w.history[b] = counts[PT_COUNTS_BASE + b];
-    w.historyBounces = std::max(w.historyBounces, std::min<int32_t>(wavefrontBounces, PT_COUNTS_MAX));
+    if (g.historyN != g.n) { g.historyN = g.n; g.historyBounces = 0; }
+    for (int32_t b = 0; b < g.wavefrontBounces && b < PT_COUNTS_MAX; ++b) g.history[b] = counts[PT_COUNTS_BASE + b];
+    g.historyBounces = std::max(g.historyBounces, std::min<int32_t>(g.wavefrontBounces, PT_COUNTS_MAX));
     if (statsOut)
     {
         statsOut->extensionRays += hs[0]; statsOut->shadowRays += hs[1]; statsOut->otherRays += hs[2];
         statsOut->tailRays += hs[5];
-        statsOut->bounces += wavefrontBounces;
-        statsOut->paths += (uint64_t)n;
+        statsOut->bounces += g.wavefrontBounces;
+        statsOut->paths += (uint64_t)g.n;
     }
-    if (traceMsOut) *traceMsOut = traceMs;
+    if (traceMsOut) *traceMsOut += traceMs;
     return PIMGPU_OK;
+}
+
+/* the whole batch as one group on the library's stream (rays, probes, lightmap texels) */
+int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
+{
+    int rc = g_lib.ensure_group(0); if (rc) return rc;
+    PathGroup& g = g_lib.groups[0];
+    const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
+    if (traceMsOut) *traceMsOut = 0.0f;
+    if ((rc = integrate_enqueue(scene, g, 0, n, maxBounces, timeTrace, -1))) { hipStreamSynchronize(g.stream); return rc; }
+    return integrate_finish(g, statsOut, traceMsOut);
+}
+
+/*
+ * An image: the pixels split into contiguous shares, one group each, so that the shares' launches overlap (PathGroup).
+ * Every path owns its slot and its Prng stream, and the scene-side accumulators the stages touch are integer atomics,
+ * so how the image is split does not change a bit of the result (tests/test_gpu_tail.py sweeps it).
+ * Share g + 1 starts once share g is `stagger` half-bounces in: the shares then sit in different phases.
+ */
+static constexpr int kDefaultGroups = 1, kDefaultStagger = 2, kDefaultGroupMinPaths = 1 << 18;
+
+int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
+{
+    /* read per call: the tests sweep them */
+    const int kImageGroups = std::max(1, std::min(kMaxGroups, env_int("PIMGPU_GROUPS", kDefaultGroups)));
+    const int kGroupStagger = env_int("PIMGPU_GROUP_STAGGER", kDefaultStagger);
+    const int kGroupMinPaths = std::max(64, env_int("PIMGPU_GROUP_MIN_PATHS", kDefaultGroupMinPaths));
+    int groups = (int)std::min<int64_t>(kImageGroups, std::max<int64_t>(1, n / kGroupMinPaths));
+    if (g_lib.trace.counting) groups = 1;           /* the work counters live in the main stream's resources */
+    if (groups <= 1) return integrate_paths(scene, n, maxBounces, statsOut, traceMsOut);
+    int rc = PIMGPU_OK;
+    for (int gi = 0; gi < groups; ++gi) if ((rc = g_lib.ensure_group(gi))) return rc;
+    const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
+    if (traceMsOut) *traceMsOut = 0.0f;
+    hipStream_t main = g_lib.stream;
+    /* what the main stream has enqueued so far (path set-up) comes first for every share */
+    hipEvent_t start = g_lib.groups[0].done;
+    PT_HIP(hipEventRecord(start, main));
+    const int32_t per = (int32_t)((((int64_t)n + groups - 1) / groups + 63) & ~(int64_t)63);
+    int used = 0;
+    for (int gi = 0; gi < groups && rc == PIMGPU_OK; ++gi)
+    {
+        const int32_t first = std::min<int64_t>(n, (int64_t)per * gi), count = std::min<int32_t>(per, n - first);
+        if (count <= 0) break;
+        PathGroup& g = g_lib.groups[gi];
+        if (gi > 0)
+        {
+            PT_HIP(hipStreamWaitEvent(g.stream, start, 0));
+            if (kGroupStagger >= 0) PT_HIP(hipStreamWaitEvent(g.stream, g_lib.groups[gi - 1].stagger, 0));
+        }
+        rc = integrate_enqueue(scene, g, first, count, maxBounces, timeTrace, kGroupStagger);
+        ++used;
+    }
+    for (int gi = used - 1; gi >= 0; --gi)
+    {
+        const int r = integrate_finish(g_lib.groups[gi], statsOut, traceMsOut);
+        if (rc == PIMGPU_OK) rc = r;
+    }
+    return rc;
 }
 
 } /* namespace pt */
@@ -984,7 +1112,7 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
-    if ((rc = integrate_paths(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr))) return rc;
+    if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr))) return rc;
     k_resolve_image<<<(n + 255) / 256, 256, 0, st>>>(w.results, n, p->sampleWeight, t->color, t->albedo, t->normal);
     PT_HIP(hipEventRecord(e1, st));
     PT_HIP(hipEventSynchronize(e1));

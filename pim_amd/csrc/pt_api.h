@@ -5,6 +5,8 @@
 #define PT_API_H
 
 #include "pt_host.h"
+#include <vector>
+#include <utility>
 
 /* PtScene (rendering/path_tracer.c:122-166) resident in HBM */
 struct PimScene
@@ -66,12 +68,30 @@ struct WorkBuffers
     int32_t* counters = nullptr;        /* [0],[1]: queue lengths; [2],[3]: slow-list lengths; device side */
     unsigned long long* stats = nullptr;/* ext, shadow, other rays */
     PimResult* results = nullptr;       /* per path slot */
-    /* queue length at the start of each wavefront bounce of the previous integrate call (host copy): the tail policy */
-    int32_t history[64] = {}; int32_t historyBounces = 0; int64_t historyN = -1;
     int ensure_rays(int64_t n);
     int ensure_paths(int64_t n);
     void release();
 };
+
+/*
+ * One share of a batch of paths, run on its own stream with its own device-side counters and traversal resources so that
+ * several shares of one image are in flight at once: the deep bounces of a share are latency-bound (few paths, long
+ * dependent launches), and another share's early, throughput-bound bounces fill the machine meanwhile.
+ * Group 0 is the library's main stream with WorkBuffers::counters/stats and Library::trace.
+ */
+struct PathGroup
+{
+    hipStream_t stream = nullptr;
+    int32_t* counters = nullptr; unsigned long long* stats = nullptr;      /* device, 256 bytes each */
+    TraceResources* trace = nullptr; TraceResources ownTrace;
+    hipEvent_t done = nullptr, stagger = nullptr;
+    /* queue length at the start of each wavefront bounce of the previous integrate call (host copy): the tail policy */
+    int32_t history[64] = {}; int32_t historyBounces = 0; int64_t historyN = -1;
+    /* the call in flight */
+    int32_t first = 0, n = 0, wavefrontBounces = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+static constexpr int kMaxGroups = 8;
 
 struct Library
 {
@@ -81,6 +101,9 @@ struct Library
     hipStream_t stream = nullptr;
     TraceResources trace;
     WorkBuffers work;
+    PathGroup groups[kMaxGroups];
+    int ensure_group(int g);
+    void release_groups();
 };
 extern Library g_lib;
 

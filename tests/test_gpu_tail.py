@@ -14,14 +14,18 @@ from tests.test_gpu_image import _render_both
 pytestmark = pytest.mark.gpu
 
 
+KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS")
+
+
 @pytest.fixture
 def tail_env():
-    old = os.environ.get("PIMGPU_TAIL_BOUNCE")
+    old = {k: os.environ.get(k) for k in KNOBS}
     yield
-    if old is None:
-        os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
-    else:
-        os.environ["PIMGPU_TAIL_BOUNCE"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("switch", ["-1", "0", "1", "3", "7"])
@@ -76,3 +80,16 @@ def test_lightmap_bake_through_the_tail_bit_exact(tail_env):
     from tests.test_gpu_lightmap import test_cornell_bake_bit_exact
     os.environ["PIMGPU_TAIL_BOUNCE"] = "1"
     test_cornell_bake_bit_exact()
+
+
+@pytest.mark.parametrize("groups,stagger,switch", [("2", "2", "3"), ("3", "1", "-1"), ("4", "0", "1"), ("8", "-1", "0")])
+def test_image_shares_on_concurrent_streams_bit_exact(tail_env, groups, stagger, switch):
+    """an image split into shares that run on their own streams (integrate_image), staggered or not, each share with
+    its own tail switch: the same bits as the oracle, ray counts included"""
+    os.environ["PIMGPU_GROUPS"] = groups
+    os.environ["PIMGPU_GROUP_STAGGER"] = stagger
+    os.environ["PIMGPU_GROUP_MIN_PATHS"] = "64"
+    os.environ["PIMGPU_TAIL_BOUNCE"] = switch
+    _render_both(scenes.cornell_box(), 128, 72, 3, 8)
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
