@@ -40,6 +40,7 @@ extern "C" {
 /* MatFlag bits, rendering/material.h:8-20 */
 #define PIM_MATFLAG_EMISSIVE   (1u << 0)
 #define PIM_MATFLAG_SKY        (1u << 1)
+#define PIM_MATFLAG_LAVA       (1u << 4)
 #define PIM_MATFLAG_REFRACTIVE (1u << 5)
 
 /* PtHitType, rendering/path_tracer.h:15-22 */
@@ -215,14 +216,17 @@ int pimgpu_work_counters(int enable, uint64_t* out);
 
 /* ---- scene inputs --------------------------------------------------------- */
 
-/* Mesh, rendering/mesh.h:25-33: the three arrays FlattenDrawables reads, float4[length] each, host */
+/* Mesh, rendering/mesh.h:25-33: the three arrays FlattenDrawables reads, float4[length] each, host; uvs.zw are the
+ * lightmap coordinates and texIndices[].w the lightmap's texture id (int4[length]; written by chartnodes_assign,
+ * lightmap.c:919-930; only pimgpu_lightmap_embed reads them, NULL = no triangle of the mesh is mapped) */
 typedef struct PimMesh
 {
-    int32_t      length;
-    int32_t      _pad;
-    const float* positions;
-    const float* normals;
-    const float* uvs;
+    int32_t        length;
+    int32_t        _pad;
+    const float*   positions;
+    const float*   normals;
+    const float*   uvs;
+    const int32_t* texIndices;
 } PimMesh;
 
 /* the columns of the Entities table FlattenDrawables reads (rendering/drawable.h:14-27) and the
@@ -354,6 +358,17 @@ int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCoun
     int32_t lmSize, float texelsPerMeter, float timeSlice, int32_t spp,
     uint32_t passIndex, uint32_t seed, int32_t maxBounces,
     int64_t texelBegin, int64_t texelEnd);
+
+/* EmbedAttributes / EmbedTaskFn (lightmap.c:941-1045), the last step of LmPack_Pack (:1092) and the producer of
+ * LmPack_Bake's inputs: every texel of every page takes the mapped triangle (texIndices[iVert].w == the page's texture
+ * id; drawables with MatFlag_Sky | MatFlag_Lava and NULL meshes skipped) whose signed 2D distance (sdTriangle2D on
+ * uvs.zw * lmSize) to the texel centre is smallest and below kFillPadding = 2 texels -- the first in drawable, vertex
+ * order on equal distance -- and keeps its barycentric position and normal (MESH space, as the reference);
+ * sampleCounts = 1 where a triangle was found, else 0, position = normal = 0.  pageTexIds[lmCount] are the pages'
+ * texture ids (Lightmap.slot.index, lightmap.h:30); NULL = page i has id i.  Writes the position | normal |
+ * sampleCounts parts of the host pages; the probes are left alone. */
+int pimgpu_lightmap_embed(const PimDrawables* drawables, const int32_t* pageTexIds, PimLightmapPage* pages,
+    int32_t lmCount, int32_t lmSize);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,17 @@ HOOK(brdf_lut_sample)
     v2 r = BrdfLutSample((int32_t)in[0], (int32_t)in[1], rcp, rcp, dx, o2(F(in, 4), F(in, 5)), F(in, 6), o2(F(in, 7), F(in, 8)));
     PF(out, 0, r.x); PF(out, 1, r.y);
 }
+HOOK(lm_embed_fragment)
+{
+    const float size = F(in, 6);
+    const v2 A = o2_muls(o2(F(in, 0), F(in, 1)), size), B = o2_muls(o2(F(in, 2), F(in, 3)), size), C = o2_muls(o2(F(in, 4), F(in, 5)), size);
+    const v2 px = o2(F(in, 7), F(in, 8));
+    v4 pos[3] = { F3(in, 9, 1.0f), F3(in, 12, 1.0f), F3(in, 15, 1.0f) }, nor[3] = { F3(in, 18, 0.0f), F3(in, 21, 0.0f), F3(in, 24, 0.0f) };
+    v4 fp, fn;
+    LmEmbedFragment(A, B, C, px, pos, nor, &fp, &fn);
+    fn = o4_normalize3(fn);
+    PF(out, 0, sdTriangle2D(A, B, C, px)); PF(out, 1, sdEdge2D(A, B, C)); P3(out, 2, fp); P3(out, 5, fn);
+}
 HOOK(f2_tent) { v2 r = f2_tent(o2(F(in, 0), F(in, 1))); PF(out, 0, r.x); PF(out, 1, r.y); }
 HOOK(Cubemap_CalcDir) { v4 d = Cubemap_CalcDir((int32_t)in[0], (int)in[1], (int32_t)in[2], (int32_t)in[3], o2(F(in, 4), F(in, 5))); PF(out, 0, d.x); PF(out, 1, d.y); PF(out, 2, d.z); }
 HOOK(AmbCube_Fit)

@@ -706,6 +706,52 @@ ORC_INL float sdTriangle3D(v4 a, v4 b, v4 c, v4 p)
     return sqrtf(o_max(t, ORC_EPS_SQ));
 }
 
+/* ---- lightmap embedding helpers: math/sdf.h:99-156, rendering/lightmap.c:1000-1019 ---- */
+ORC_INL float o2_dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }                                /* float2_funcs.h:303 */
+ORC_INL v2 o2_min(v2 a, v2 b) { return o2(o_min(a.x, b.x), o_min(a.y, b.y)); }                    /* :253 */
+ORC_INL float sdEdge2D(v2 A, v2 B, v2 P)                                                          /* sdf.h:99-108 */
+{
+    v2 AP = o2_sub(P, A), AB = o2_sub(B, A);
+    float e = AP.y * AB.x - AP.x * AB.y;
+    return 0.5f * e;
+}
+ORC_INL v4 bary2D(v2 a, v2 b, v2 c, float rcpArea, v2 p)                                          /* :112-123 */
+{
+    float w = sdEdge2D(b, c, p) * rcpArea;
+    float u = sdEdge2D(c, a, p) * rcpArea;
+    float v = sdEdge2D(a, b, p) * rcpArea;
+    return o4(w, u, v, 0.0f);
+}
+ORC_INL float sdTriangle2D(v2 a, v2 b, v2 c, v2 p)                                                /* :125-156 */
+{
+    v2 ba = o2_sub(b, a), cb = o2_sub(c, b), ac = o2_sub(a, c);
+    v2 pa = o2_sub(p, a), pb = o2_sub(p, b), pc = o2_sub(p, c);
+    float h0 = o_sat(o2_dot(pa, ba) / o2_dot(ba, ba));
+    float h1 = o_sat(o2_dot(pb, cb) / o2_dot(cb, cb));
+    float h2 = o_sat(o2_dot(pc, ac) / o2_dot(ac, ac));
+    v2 pq0 = o2_sub(pa, o2_muls(ba, h0));
+    v2 pq1 = o2_sub(pb, o2_muls(cb, h1));
+    v2 pq2 = o2_sub(pc, o2_muls(ac, h2));
+    float s = o_sign(ba.x * ac.y - ba.y * ac.x);
+    v2 t0 = o2(o2_dot(pq0, pq0), s * (pa.x * ba.y - pa.y * ba.x));
+    v2 t1 = o2(o2_dot(pq1, pq1), s * (pb.x * cb.y - pb.y * cb.x));
+    v2 t2 = o2(o2_dot(pq2, pq2), s * (pc.x * ac.y - pc.y * ac.x));
+    v2 d = o2_min(t0, o2_min(t1, t2));
+    float dySign = (d.y >= 0.0f) ? 1.0f : -1.0f;
+    return -sqrtf(o_max(d.x, ORC_EPS_SQ)) * dySign;
+}
+#define ORC_LM_FILL_PADDING 2.0f                                                                  /* lightmap.c:40 */
+/* the fragment EmbedTaskFn keeps for a texel once triangle (A, B, C) (texel units) has won it, lightmap.c:1007-1014 */
+ORC_INL void LmEmbedFragment(v2 A, v2 B, v2 C, v2 px, const v4* pos, const v4* nor, v4* fragPos, v4* fragNor)
+{
+    float area = sdEdge2D(A, B, C);
+    area = o_max(area, 1e-5f);
+    v4 wuv = bary2D(A, B, C, 1.0f / area, px);
+    wuv = o4_divs(wuv, wuv.x + wuv.y + wuv.z);
+    *fragPos = o4_blend(pos[0], pos[1], pos[2], wuv);
+    *fragNor = o4_normalize3(o4_blend(nor[0], nor[1], nor[2], wuv));
+}
+
 /* ---- participating media helpers: math/atmosphere.h:36-43, math/noise.h:16-83 ---- */
 ORC_INL float MiePhase(float cosTheta, float g)
 {

@@ -1884,3 +1884,78 @@ void orc_brdf_lut_bake(float* texels, int32_t sx, int32_t sy, int32_t prevSample
 float orc_test_dist_bake(float* pdf, float* cdf, int32_t len) { return dist_bake(pdf, cdf, len); }
 int32_t orc_test_dist_find(const float* cdf, int32_t size, float u) { return dist_find_interval(cdf, size, u); }
 void orc_test_dist_update(float* pdf, float* cdf, uint32_t* live, int32_t len, uint32_t* sum, float* integral) { dist_update(pdf, cdf, live, len, sum, integral); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* EmbedAttributes, rendering/lightmap.c:941-1045                                              */
+
+typedef struct { const PimDrawables* d; const int32_t* pageTexIds; PimLightmapPage* pages; int32_t lmSize; } EmbedTask;
+
+static void embed_fn(void* user, int64_t begin, int64_t end, int tid)
+{
+    (void)tid;
+    const EmbedTask* t = (const EmbedTask*)user;
+    const PimDrawables* d = t->d;
+    const int32_t lmSize = t->lmSize;
+    const int64_t lmLen = (int64_t)lmSize * lmSize;
+    const float texelSize = (float)lmSize;
+    for (int64_t iWork = begin; iWork < end; ++iWork)                       /* :960-1031 */
+    {
+        const int32_t iLightmap = (int32_t)(iWork / lmLen);
+        const int32_t iTexel = (int32_t)(iWork % lmLen);
+        const int32_t x = iTexel % lmSize, y = iTexel / lmSize;
+        const v2 pxCenter = o2(x + 0.5f, y + 0.5f);
+        const int32_t lmTxId = t->pageTexIds ? t->pageTexIds[iLightmap] : iLightmap;
+        v4 lmPos = o4_s(0.0f), lmNor = o4_s(0.0f);
+        float lmDist = (float)(1 << 23);
+        for (int32_t iDraw = 0; iDraw < d->count; ++iDraw)
+        {
+            if (d->materials[iDraw].flags & (PIM_MATFLAG_SKY | PIM_MATFLAG_LAVA)) continue;      /* kUnmappedMaterials, :38 */
+            if (d->meshes[iDraw] < 0) continue;
+            const PimMesh* mesh = &d->meshTable[d->meshes[iDraw]];
+            if (!mesh->texIndices) continue;
+            for (int32_t iVert = 0; (iVert + 3) <= mesh->length; iVert += 3)
+            {
+                if (mesh->texIndices[(size_t)iVert * 4 + 3] != lmTxId) continue;
+                const float* ua = mesh->uvs + (size_t)iVert * 4;
+                const v2 A = o2_muls(o2(ua[2], ua[3]), texelSize), B = o2_muls(o2(ua[6], ua[7]), texelSize), C = o2_muls(o2(ua[10], ua[11]), texelSize);
+                /* Not in the reference: a texel more than 3 texels outside the triangle's bounds cannot pass the test below,
+                 * and skipping it changes no result, only the oracle's running time -- PROVIDED the triangle is not a
+                 * sliver.  sdTriangle2D calls a point inside when none of its three edge cross products comes out negative;
+                 * each is exact to a relative 5e-7 of |p - v| |edge|, a point that far outside is on the outer side of an
+                 * edge line by an angle of at least half the sharpest corner, so the sign holds while every corner is wider
+                 * than ~1e-6 rad.  Below 1e-5 rad (zero area included: then EVERY texel gets a negative distance, the
+                 * reference's behaviour), or with coordinates that are not finite or huge, nothing is skipped. */
+                {
+                    const v2 ba = o2_sub(B, A), cb = o2_sub(C, B), ac = o2_sub(A, C);
+                    const float area2 = o_abs(ba.x * ac.y - ba.y * ac.x);
+                    const float lmax2 = o_max(o2_dot(ba, ba), o_max(o2_dot(cb, cb), o2_dot(ac, ac)));
+                    const float lox = o_min(A.x, o_min(B.x, C.x)), hix = o_max(A.x, o_max(B.x, C.x));
+                    const float loy = o_min(A.y, o_min(B.y, C.y)), hiy = o_max(A.y, o_max(B.y, C.y));
+                    const int bounded = (area2 > 1.0e-5f * lmax2) && lox > -1.0e5f && loy > -1.0e5f && hix < 1.0e5f && hiy < 1.0e5f;
+                    if (bounded && (pxCenter.x < lox - 3.0f || pxCenter.x > hix + 3.0f || pxCenter.y < loy - 3.0f || pxCenter.y > hiy + 3.0f)) continue;
+                }
+                const float dist = sdTriangle2D(A, B, C, pxCenter);
+                if (dist < ORC_LM_FILL_PADDING && dist < lmDist)
+                {
+                    v4 pos[3] = { ld4(mesh->positions, iVert), ld4(mesh->positions, iVert + 1), ld4(mesh->positions, iVert + 2) };
+                    v4 nor[3] = { ld4(mesh->normals, iVert), ld4(mesh->normals, iVert + 1), ld4(mesh->normals, iVert + 2) };
+                    LmEmbedFragment(A, B, C, pxCenter, pos, nor, &lmPos, &lmNor);
+                    lmDist = dist;
+                }
+            }
+        }
+        if (lmDist < ORC_LM_FILL_PADDING) lmNor = o4_normalize3(lmNor);
+        float* block = t->pages[iLightmap].block;
+        float* position = block + (size_t)lmLen * 20; float* normal = block + (size_t)lmLen * 23; float* sampleCounts = block + (size_t)lmLen * 26;
+        sampleCounts[iTexel] = lmDist < ORC_LM_FILL_PADDING ? 1.0f : 0.0f;
+        position[(size_t)iTexel * 3 + 0] = lmPos.x; position[(size_t)iTexel * 3 + 1] = lmPos.y; position[(size_t)iTexel * 3 + 2] = lmPos.z;
+        normal[(size_t)iTexel * 3 + 0] = lmNor.x; normal[(size_t)iTexel * 3 + 1] = lmNor.y; normal[(size_t)iTexel * 3 + 2] = lmNor.z;
+    }
+}
+
+void orc_lightmap_embed(const PimDrawables* drawables, const int32_t* pageTexIds, PimLightmapPage* pages,
+    int32_t lmCount, int32_t lmSize, int threads)
+{
+    EmbedTask t = { drawables, pageTexIds, pages, lmSize };
+    orc_parallel_for(embed_fn, &t, (int64_t)lmCount * lmSize * lmSize, threads);
+}

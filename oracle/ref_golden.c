@@ -379,6 +379,36 @@ int main(int argc, char** argv)
     }
     end("brdf_lut_sample", N, 9, 2);
 
+    /* ---- lightmap embedding: sdf.h's 2D functions and the fragment EmbedTaskFn keeps (rendering/lightmap.c:1000-1025;
+     * the function itself is static in a translation unit that needs the Vulkan headers, so the record evaluates the
+     * reference's own header functions in the order that loop calls them).  Every 8th case has a zero-length edge. ---- */
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        const float size = (i & 1) ? 1024.0f : 64.0f;
+        float2 ua = { rnd(), rnd() }, ub = { rnd(), rnd() }, uc = { rnd(), rnd() };
+        if ((i & 3) == 1) { ub.x = ua.x + rnds(-4, 4) / size; ub.y = ua.y + rnds(-4, 4) / size; uc.x = ua.x + rnds(-4, 4) / size; uc.y = ua.y + rnds(-4, 4) / size; }
+        if ((i & 7) == 7) ub = ua;
+        const float2 A = f2_mulvs(ua, size), B = f2_mulvs(ub, size), C = f2_mulvs(uc, size);
+        float2 px = { (float)(i32)(rnd() * size) + 0.5f, (float)(i32)(rnd() * size) + 0.5f };
+        if (i & 2) { px.x = (float)(i32)A.x + 0.5f + (float)((i32)(nextu() % 5u) - 2); px.y = (float)(i32)A.y + 0.5f + (float)((i32)(nextu() % 5u) - 2); }
+        float4 pa = f4_v(rnds(-50, 50), rnds(-50, 50), rnds(-50, 50), 1.0f), pb = f4_v(rnds(-50, 50), rnds(-50, 50), rnds(-50, 50), 1.0f), pc = f4_v(rnds(-50, 50), rnds(-50, 50), rnds(-50, 50), 1.0f);
+        float4 na = rndunit(), nb = rndunit(), nc = rndunit();
+        const float dist = sdTriangle2D(A, B, C, px);
+        float area = sdEdge2D(A, B, C);
+        const float rawArea = area;
+        area = pim_max(area, 1e-5f);
+        float4 wuv = bary2D(A, B, C, 1.0f / area, px);
+        wuv = f4_divvs(wuv, wuv.x + wuv.y + wuv.z);
+        const float4 fragPos = f4_blend(pa, pb, pc, wuv);
+        float4 fragNor = f4_normalize3(f4_blend(na, nb, nc, wuv));
+        fragNor = f4_normalize3(fragNor);
+        putf(ua.x); putf(ua.y); putf(ub.x); putf(ub.y); putf(uc.x); putf(uc.y); putf(size); putf(px.x); putf(px.y);
+        PUT3(pa); PUT3(pb); PUT3(pc); PUT3(na); PUT3(nb); PUT3(nc);
+        putf(dist); putf(rawArea); PUT3(fragPos); PUT3(fragNor);
+    }
+    end("lm_embed_fragment", N, 27, 8);
+
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);
     fclose(s_out);

@@ -79,7 +79,7 @@ class PimTraceStats(C.Structure):
 
 class PimMesh(C.Structure):
     _fields_ = [("length", C.c_int32), ("_pad", C.c_int32), ("positions", C.c_void_p), ("normals", C.c_void_p),
-                ("uvs", C.c_void_p)]
+                ("uvs", C.c_void_p), ("texIndices", C.c_void_p)]
 
 
 class PimDrawables(C.Structure):
@@ -106,7 +106,7 @@ EXPORTS = [
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
-    "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake",
+    "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
 ]
 
@@ -296,18 +296,27 @@ class Trace:
 
 class Drawables:
     """the Entities columns + mesh table FlattenDrawables reads (rendering/drawable.h:14-27, mesh.h:25-33), kept alive
-    as numpy arrays behind a PimDrawables struct.  meshes: list of (positions, normals, uvs) float32 (len,4) arrays;
+    as numpy arrays behind a PimDrawables struct.  meshes: list of (positions, normals, uvs) float32 (len,4) arrays,
+    optionally with a fourth int32 (len,4) array, texIndices (lightmap id in .w; only lightmap_embed reads it);
     mesh_ids: per entity index into meshes (-1 = no mesh); matrices: (count,4,4) float32 with matrices[i][c] = column c."""
 
     def __init__(self, meshes, mesh_ids, matrices, materials):
         self.keep = []
+        self.mesh_arrays = []                     # per mesh: (positions, normals, uvs, texIndices or None) as uploaded
         self.table = (PimMesh * max(1, len(meshes)))()
-        for i, (P, N, U) in enumerate(meshes):
-            P, N, U = f32(P), f32(N), f32(U)
+        for i, mesh in enumerate(meshes):
+            P, N, U = f32(mesh[0]), f32(mesh[1]), f32(mesh[2])
             assert P.shape == N.shape == U.shape and (P.ndim == 2 and P.shape[1] == 4 or P.size == 0)
             self.keep += [P, N, U]
             self.table[i].length = P.shape[0]
             self.table[i].positions, self.table[i].normals, self.table[i].uvs = P.ctypes.data, N.ctypes.data, U.ctypes.data
+            T = None
+            if len(mesh) > 3 and mesh[3] is not None:
+                T = np.ascontiguousarray(mesh[3], np.int32)
+                assert T.shape == P.shape
+                self.keep.append(T)
+                self.table[i].texIndices = T.ctypes.data
+            self.mesh_arrays.append((P, N, U, T))
         self.mesh_ids = np.ascontiguousarray(mesh_ids, np.int32)
         self.matrices = f32(matrices).reshape(-1, 16)
         self.materials = (PimMaterial * max(1, len(materials)))(*materials)
@@ -335,6 +344,24 @@ def flatten(drawables):
     mats = (PimMaterial * max(1, M))()
     check(load_library().pimgpu_flatten(C.byref(drawables.desc), _ptr(P), _ptr(N), _ptr(U), _ptr(ids), mats), "pimgpu_flatten")
     return P, N, U, ids, mats
+
+
+def _page_array(pages, lmSize):
+    arr = (PimLightmapPage * max(1, len(pages)))()
+    for i, p in enumerate(pages):
+        assert p.dtype == np.float32 and p.flags["C_CONTIGUOUS"] and p.size == lmSize * lmSize * 27
+        arr[i].block = p.ctypes.data
+    return arr
+
+
+def lightmap_embed(drawables, pages, lmSize, page_tex_ids=None):
+    """EmbedAttributes (rendering/lightmap.c:941-1045) on the GPU: fills position | normal | sampleCounts of the pages
+    (float32 arrays of lmSize*lmSize*27 floats each, the reference's page layout) from the meshes' uvs.zw / texIndices.w"""
+    ids = None if page_tex_ids is None else np.ascontiguousarray(page_tex_ids, np.int32)
+    assert ids is None or ids.shape == (len(pages),)
+    check(load_library().pimgpu_lightmap_embed(C.byref(drawables.desc), None if ids is None else _ptr(ids),
+          _page_array(pages, lmSize), C.c_int32(len(pages)), C.c_int32(lmSize)), "pimgpu_lightmap_embed")
+    return pages
 
 
 def brdf_lut_bake(texels, prevSamples, numSamples, seed=0):

@@ -90,6 +90,130 @@ __global__ __launch_bounds__(256) void k_brdf_lut(v2* __restrict__ texels, int32
     texels[iTexel] = f2_lerps(old, result, dt);                      /* f2_lerpvs */
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* EmbedAttributes / EmbedTaskFn, rendering/lightmap.c:941-1045                                    */
+
+/*
+ * The reference gives every texel a loop over every triangle of every drawable (O(texels x triangles)) and keeps the
+ * nearest one within kFillPadding, the first in drawable/vertex order on a tie.  That winner is the minimum of the
+ * pair (distance, order of the triangle in that loop), so the loop turns inside out: one wave per mapped triangle
+ * walks only the texels its padded bounds cover and folds (distance, order) into the texel's 64-bit key with an
+ * atomic min; a second pass, one lane per texel, rebuilds the winner's fragment.  Same fp32 operations in the same
+ * order per (texel, triangle) pair, so the pages equal the scalar loop's bit for bit.
+ */
+struct DEmbedEntity
+{
+    const v4* positions; const v4* normals; const v4* uvs;   /* Mesh arrays in HBM; uvs.zw = lightmap coordinates */
+    const int4* texIndices;                                  /* .w = lightmap texture id of the triangle */
+    uint32_t triFirst;                                       /* order of the entity's first triangle in the reference's loop */
+    int32_t triCount;
+};
+
+struct EmbedArgs
+{
+    const DEmbedEntity* entities; int32_t entityCount;
+    uint32_t triTotal;
+    const int32_t* pageTexIds; int32_t lmCount, lmSize;
+    unsigned long long* keys;                                /* [lmCount * lmSize^2], starts all ones = no triangle */
+    float* position; float* normal; float* sampleCounts;     /* float3 / float3 / float per texel, all pages */
+};
+
+__device__ __forceinline__ int32_t embed_entity_of(const EmbedArgs& a, uint32_t tri)
+{
+    int32_t lo = 0, hi = a.entityCount - 1;                  /* last entity whose triFirst <= tri */
+    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (a.entities[mid].triFirst <= tri) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+/* fp32 bits -> u32 that orders like the float (no NaN reaches it) */
+__device__ __forceinline__ uint32_t embed_order_bits(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+static constexpr int kEmbedThreads = 256;
+
+__global__ __launch_bounds__(kEmbedThreads) void k_embed_raster(EmbedArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wavesTotal = gridDim.x * (kEmbedThreads / 64);
+    const float texelSize = (float)a.lmSize;
+    const int64_t lmLen = (int64_t)a.lmSize * a.lmSize;
+    for (uint32_t tri = blockIdx.x * (kEmbedThreads / 64) + (threadIdx.x >> 6); tri < a.triTotal; tri += wavesTotal)
+    {
+        const DEmbedEntity e = a.entities[embed_entity_of(a, tri)];
+        const int32_t iVert = (int32_t)(tri - e.triFirst) * 3;
+        const int32_t texId = e.texIndices[iVert].w;
+        int32_t page = -1;
+        for (int32_t i = 0; i < a.lmCount; ++i) if ((a.pageTexIds ? a.pageTexIds[i] : i) == texId) { page = i; break; }
+        if (page < 0) continue;
+        /* several pages may share an id only by caller error; the reference would then fill each: not supported, first wins */
+        const v4 ua = e.uvs[iVert], ub = e.uvs[iVert + 1], uc = e.uvs[iVert + 2];
+        const v2 A = f2_muls(f2_v(ua.z, ua.w), texelSize), B = f2_muls(f2_v(ub.z, ub.w), texelSize), C = f2_muls(f2_v(uc.z, uc.w), texelSize);
+        /* Texels whose centre can pass the test below: the bounds grown by 3 texels (walked with one more of slack).
+         * That holds unless the triangle is a sliver: sdTriangle2D calls a point inside when none of its three edge
+         * cross products comes out negative; each is exact to a relative 5e-7 of |p - v| |edge|, and a point that far
+         * outside is on the outer side of an edge line by an angle of at least half the sharpest corner, so the sign
+         * holds while every corner is wider than ~1e-6 rad.  Below 1e-5 rad (zero area included: the reference then
+         * gives EVERY texel a negative distance), or with coordinates that are not finite or huge: the whole page. */
+        const v2 ba = f2_sub(B, A), cb = f2_sub(C, B), ac = f2_sub(A, C);
+        const float area2 = f1_abs(ba.x * ac.y - ba.y * ac.x);
+        const float lmax2 = f1_max(f2_dot(ba, ba), f1_max(f2_dot(cb, cb), f2_dot(ac, ac)));
+        const float lox = f1_min(A.x, f1_min(B.x, C.x)), hix = f1_max(A.x, f1_max(B.x, C.x));
+        const float loy = f1_min(A.y, f1_min(B.y, C.y)), hiy = f1_max(A.y, f1_max(B.y, C.y));
+        const bool bounded = (area2 > 1.0e-5f * lmax2) && lox > -1.0e5f && loy > -1.0e5f && hix < 1.0e5f && hiy < 1.0e5f;
+        int32_t x0 = 0, x1 = a.lmSize - 1, y0 = 0, y1 = a.lmSize - 1;
+        if (bounded)
+        {
+            x0 = (int32_t)f1_max(lox - 4.0f, 0.0f); y0 = (int32_t)f1_max(loy - 4.0f, 0.0f);
+            x1 = (int32_t)f1_min(hix + 4.0f, (float)(a.lmSize - 1)); y1 = (int32_t)f1_min(hiy + 4.0f, (float)(a.lmSize - 1));
+        }
+        const int32_t w = x1 - x0 + 1, h = y1 - y0 + 1;
+        if (w <= 0 || h <= 0) continue;
+        const int64_t cells = (int64_t)w * h;
+        for (int64_t c = lane; c < cells; c += 64)
+        {
+            const int32_t x = x0 + (int32_t)(c % w), y = y0 + (int32_t)(c / w);
+            const float dist = sdTriangle2D(A, B, C, f2_v(x + 0.5f, y + 0.5f));
+            if (dist < PT_LM_FILL_PADDING)
+            {
+                const unsigned long long key = ((unsigned long long)embed_order_bits(dist) << 32) | (unsigned long long)tri;
+                atomicMin(&a.keys[(int64_t)page * lmLen + (int64_t)y * a.lmSize + x], key);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_embed_resolve(EmbedArgs a)
+{
+    const int64_t lmLen = (int64_t)a.lmSize * a.lmSize;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lmLen * a.lmCount) return;
+    const unsigned long long key = a.keys[i];
+    v4 lmPos = f4_s(0.0f), lmNor = f4_s(0.0f);
+    float count = 0.0f;
+    if (key != ~0ull)
+    {
+        const uint32_t tri = (uint32_t)key;
+        const DEmbedEntity e = a.entities[embed_entity_of(a, tri)];
+        const int32_t iVert = (int32_t)(tri - e.triFirst) * 3;
+        const int32_t iTexel = (int32_t)(i % lmLen);
+        const float texelSize = (float)a.lmSize;
+        const v4 ua = e.uvs[iVert], ub = e.uvs[iVert + 1], uc = e.uvs[iVert + 2];
+        const v2 A = f2_muls(f2_v(ua.z, ua.w), texelSize), B = f2_muls(f2_v(ub.z, ub.w), texelSize), C = f2_muls(f2_v(uc.z, uc.w), texelSize);
+        const v2 px = f2_v((iTexel % a.lmSize) + 0.5f, (iTexel / a.lmSize) + 0.5f);
+        const v4 pos[3] = { e.positions[iVert], e.positions[iVert + 1], e.positions[iVert + 2] };
+        const v4 nor[3] = { e.normals[iVert], e.normals[iVert + 1], e.normals[iVert + 2] };
+        LmEmbedFragment(A, B, C, px, pos, nor, &lmPos, &lmNor);
+        lmNor = f4_normalize3(lmNor);                                    /* :1023-1026 */
+        count = 1.0f;
+    }
+    a.sampleCounts[i] = count;
+    a.position[i * 3 + 0] = lmPos.x; a.position[i * 3 + 1] = lmPos.y; a.position[i * 3 + 2] = lmPos.z;
+    a.normal[i * 3 + 0] = lmNor.x; a.normal[i * 3 + 1] = lmNor.y; a.normal[i * 3 + 2] = lmNor.z;
+}
+
 } /* namespace pt */
 
 using namespace pt;
@@ -220,6 +344,82 @@ int pimgpu_brdf_lut_bake(float* texels, int32_t width, int32_t height, int32_t p
     PT_HIP(hipGetLastError());
     PT_HIP(hipMemcpyAsync(texels, buf.p, sizeof(v2) * (size_t)n, hipMemcpyDeviceToHost, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
+int pimgpu_lightmap_embed(const PimDrawables* d, const int32_t* pageTexIds, PimLightmapPage* pages, int32_t lmCount, int32_t lmSize)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if ((rc = flatten_validate(d, "lightmap_embed"))) return rc;
+    if (lmCount < 0 || lmSize <= 0 || lmSize > 16384 || (lmCount > 0 && !pages)) { set_error("lightmap_embed: bad page arguments"); return PIMGPU_E_INVALID; }
+    for (int32_t i = 0; i < lmCount; ++i) if (!pages[i].block) { set_error("lightmap_embed: page %d has no block", i); return PIMGPU_E_INVALID; }
+    if (lmCount == 0) return PIMGPU_OK;
+    hipStream_t st = g_lib.stream;
+    const int64_t lmLen = (int64_t)lmSize * lmSize, texels = lmLen * lmCount;
+
+    /* the drawables EmbedTaskFn does not skip (:976-984), in its order; every mesh goes to HBM once */
+    std::vector<DevBuf> meshBufs((size_t)d->meshCount);
+    std::vector<DEmbedEntity> ents;
+    uint64_t triTotal = 0;
+    for (int32_t i = 0; i < d->count; ++i)
+    {
+        const int32_t m = d->meshes[i];
+        if (m < 0 || (d->materials[i].flags & (PIM_MATFLAG_SKY | PIM_MATFLAG_LAVA))) continue;
+        const PimMesh& mesh = d->meshTable[m];
+        if (!mesh.texIndices || mesh.length < 3) continue;
+        const size_t bytes = sizeof(v4) * (size_t)mesh.length;
+        if (!meshBufs[(size_t)m].p)
+        {
+            if ((rc = meshBufs[(size_t)m].alloc(bytes * 4))) return rc;
+            char* base = (char*)meshBufs[(size_t)m].p;
+            PT_HIP(hipMemcpyAsync(base, mesh.positions, bytes, hipMemcpyHostToDevice, st));
+            PT_HIP(hipMemcpyAsync(base + bytes, mesh.normals, bytes, hipMemcpyHostToDevice, st));
+            PT_HIP(hipMemcpyAsync(base + 2 * bytes, mesh.uvs, bytes, hipMemcpyHostToDevice, st));
+            PT_HIP(hipMemcpyAsync(base + 3 * bytes, mesh.texIndices, bytes, hipMemcpyHostToDevice, st));
+        }
+        char* base = (char*)meshBufs[(size_t)m].p;
+        DEmbedEntity e;
+        e.positions = (const v4*)base; e.normals = (const v4*)(base + bytes); e.uvs = (const v4*)(base + 2 * bytes);
+        e.texIndices = (const int4*)(base + 3 * bytes);
+        e.triFirst = (uint32_t)triTotal; e.triCount = mesh.length / 3;
+        triTotal += (uint64_t)e.triCount;
+        ents.push_back(e);
+    }
+    if (triTotal > 0xfffffff0ull) { set_error("lightmap_embed: %llu triangles exceed the 32-bit triangle order", (unsigned long long)triTotal); return PIMGPU_E_LIMIT; }
+
+    DevBuf entBuf, idBuf, keyBuf, outBuf;
+    if ((rc = entBuf.alloc(sizeof(DEmbedEntity) * ents.size()))) return rc;
+    if ((rc = keyBuf.alloc(sizeof(unsigned long long) * (size_t)texels))) return rc;
+    if ((rc = outBuf.alloc(sizeof(float) * 7 * (size_t)texels))) return rc;
+    if (!ents.empty()) PT_HIP(hipMemcpyAsync(entBuf.p, ents.data(), sizeof(DEmbedEntity) * ents.size(), hipMemcpyHostToDevice, st));
+    if (pageTexIds)
+    {
+        if ((rc = idBuf.alloc(sizeof(int32_t) * (size_t)lmCount))) return rc;
+        PT_HIP(hipMemcpyAsync(idBuf.p, pageTexIds, sizeof(int32_t) * (size_t)lmCount, hipMemcpyHostToDevice, st));
+    }
+    PT_HIP(hipMemsetAsync(keyBuf.p, 0xff, sizeof(unsigned long long) * (size_t)texels, st));
+    EmbedArgs a;
+    a.entities = (const DEmbedEntity*)entBuf.p; a.entityCount = (int32_t)ents.size(); a.triTotal = (uint32_t)triTotal;
+    a.pageTexIds = pageTexIds ? (const int32_t*)idBuf.p : nullptr; a.lmCount = lmCount; a.lmSize = lmSize;
+    a.keys = (unsigned long long*)keyBuf.p;
+    a.position = (float*)outBuf.p; a.normal = a.position + 3 * texels; a.sampleCounts = a.normal + 3 * texels;
+    if (triTotal > 0)
+    {
+        const int64_t wantBlocks = ((int64_t)triTotal + (kEmbedThreads / 64) - 1) / (kEmbedThreads / 64);
+        const int blocks = (int)std::min<int64_t>(wantBlocks, (int64_t)g_lib.cuCount * 64);
+        k_embed_raster<<<blocks, kEmbedThreads, 0, st>>>(a);
+        PT_HIP(hipGetLastError());
+    }
+    k_embed_resolve<<<(unsigned)((texels + 255) / 256), 256, 0, st>>>(a);
+    PT_HIP(hipGetLastError());
+    for (int32_t i = 0; i < lmCount; ++i)
+    {
+        float* block = pages[i].block;                                 /* [5][S*S] float4 | float3 position | float3 normal | float counts */
+        PT_HIP(hipMemcpyAsync(block + lmLen * 20, a.position + 3 * lmLen * i, sizeof(float) * 3 * (size_t)lmLen, hipMemcpyDeviceToHost, st));
+        PT_HIP(hipMemcpyAsync(block + lmLen * 23, a.normal + 3 * lmLen * i, sizeof(float) * 3 * (size_t)lmLen, hipMemcpyDeviceToHost, st));
+        PT_HIP(hipMemcpyAsync(block + lmLen * 26, a.sampleCounts + lmLen * i, sizeof(float) * (size_t)lmLen, hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(hipStreamSynchronize(st));
     return PIMGPU_OK;
 }
 

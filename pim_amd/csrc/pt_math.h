@@ -815,6 +815,52 @@ PT_FN void AmbCube_Fit(AmbCube& c, float weight, v4 dir, v4 rad)
     if (fz) c.Values[4] = f4_lerps(c.Values[4], rad, dir.z); else c.Values[5] = f4_lerps(c.Values[5], rad, dir.z);
 }
 
+/* ---- lightmap embedding helpers: math/sdf.h:99-156, rendering/lightmap.c:1000-1019 ---- */
+PT_FN float f2_dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }                                  /* float2_funcs.h:303 */
+PT_FN v2 f2_min(v2 a, v2 b) { return f2_v(f1_min(a.x, b.x), f1_min(a.y, b.y)); }                  /* :253 */
+PT_FN float sdEdge2D(v2 A, v2 B, v2 P)                                                            /* sdf.h:99-108 */
+{
+    v2 AP = f2_sub(P, A), AB = f2_sub(B, A);
+    float e = AP.y * AB.x - AP.x * AB.y;
+    return 0.5f * e;
+}
+PT_FN v4 bary2D(v2 a, v2 b, v2 c, float rcpArea, v2 p)                                            /* :112-123 */
+{
+    float w = sdEdge2D(b, c, p) * rcpArea;
+    float u = sdEdge2D(c, a, p) * rcpArea;
+    float v = sdEdge2D(a, b, p) * rcpArea;
+    return f4_v(w, u, v, 0.0f);
+}
+PT_FN float sdTriangle2D(v2 a, v2 b, v2 c, v2 p)                                                  /* :125-156 */
+{
+    v2 ba = f2_sub(b, a), cb = f2_sub(c, b), ac = f2_sub(a, c);
+    v2 pa = f2_sub(p, a), pb = f2_sub(p, b), pc = f2_sub(p, c);
+    float h0 = f1_sat(f2_dot(pa, ba) / f2_dot(ba, ba));
+    float h1 = f1_sat(f2_dot(pb, cb) / f2_dot(cb, cb));
+    float h2 = f1_sat(f2_dot(pc, ac) / f2_dot(ac, ac));
+    v2 pq0 = f2_sub(pa, f2_muls(ba, h0));
+    v2 pq1 = f2_sub(pb, f2_muls(cb, h1));
+    v2 pq2 = f2_sub(pc, f2_muls(ac, h2));
+    float s = f1_sign(ba.x * ac.y - ba.y * ac.x);
+    v2 t0 = f2_v(f2_dot(pq0, pq0), s * (pa.x * ba.y - pa.y * ba.x));
+    v2 t1 = f2_v(f2_dot(pq1, pq1), s * (pb.x * cb.y - pb.y * cb.x));
+    v2 t2 = f2_v(f2_dot(pq2, pq2), s * (pc.x * ac.y - pc.y * ac.x));
+    v2 d = f2_min(t0, f2_min(t1, t2));
+    float dySign = (d.y >= 0.0f) ? 1.0f : -1.0f;
+    return -pt_sqrt(f1_max(d.x, PT_EPS_SQ)) * dySign;
+}
+#define PT_LM_FILL_PADDING 2.0f                                                                   /* lightmap.c:40 */
+/* the fragment EmbedTaskFn keeps for a texel once triangle (A, B, C) (texel units) has won it, lightmap.c:1007-1014 */
+PT_FN void LmEmbedFragment(v2 A, v2 B, v2 C, v2 px, const v4* pos, const v4* nor, v4* fragPos, v4* fragNor)
+{
+    float area = sdEdge2D(A, B, C);
+    area = f1_max(area, 1e-5f);
+    v4 wuv = bary2D(A, B, C, 1.0f / area, px);
+    wuv = f4_divs(wuv, wuv.x + wuv.y + wuv.z);
+    *fragPos = f4_blend(pos[0], pos[1], pos[2], wuv);
+    *fragNor = f4_normalize3(f4_blend(nor[0], nor[1], nor[2], wuv));
+}
+
 /* ---- geometry helpers: math/area.h:28, math/sdf.h:158-189 ---- */
 PT_FN float TriArea3D(v4 A, v4 B, v4 C) { return 0.5f * f4_length3(f4_cross3(f4_sub(B, A), f4_sub(C, A))); }
 PT_FN float sdTriangle3D(v4 a, v4 b, v4 c, v4 p)

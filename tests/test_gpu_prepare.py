@@ -104,3 +104,77 @@ def test_gpu_prepared_inputs_render_bit_exact():
     assert_bits_equal(tr.download()[0], img[0], "colour of the GPU-prepared scene")
     assert img[0].mean() > 0.01
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# EmbedAttributes (rendering/lightmap.c:941-1045)
+
+def _embed_both(dr, count, S, ids=None, fill=-3.0):
+    gpu_init()
+    from tests import prepare_util as pu
+    got = api.lightmap_embed(dr, pu.new_pages(count, S, fill), S, ids)
+    want = pu.oracle_embed(load_oracle(True), dr, pu.new_pages(count, S, fill), S, ids)
+    for i in range(count):
+        g, w = pu.page_parts(got[i], S), pu.page_parts(want[i], S)
+        assert (g[0] == fill).all()                                           # the probes are not touched
+        assert_bits_equal(g[3], w[3], f"page {i} sampleCounts")
+        # NaN (a fragment of a zero-area triangle divides 0 by 0): only its sign/payload may differ
+        for k, what in ((1, "position"), (2, "normal")):
+            nan = np.isnan(w[k])
+            assert (np.isnan(g[k]) == nan).all(), f"page {i} {what}: NaN pattern"
+            assert_bits_equal(np.where(nan, 0.0, g[k]).astype(np.float32), np.where(nan, 0.0, w[k]).astype(np.float32), f"page {i} {what}")
+    return got
+
+
+@pytest.mark.parametrize("S,ids,tris,hard", [(64, [0, 1], (60, 200), True), (48, [9, 4, 7], (300, 500), True),
+                                             (256, [0, 1], (3000, 2000), False), (16, [5], (12, 12), True)])
+def test_lightmap_embed_bit_exact(S, ids, tris, hard):
+    """nearest triangle within the padding, first in drawable/vertex order on ties, duplicates, zero-area triangles
+    (which flood their page, as in the reference), page ids that name no page, skipped drawables"""
+    from tests import prepare_util as pu
+    dr = pu.embed_table(S, ids, tris_per_mesh=tris, hard_cases=hard)
+    pages = _embed_both(dr, len(ids), S, None if ids == list(range(len(ids))) else ids)
+    cover = [pu.page_parts(p, S)[3].mean() for p in pages]
+    assert max(cover) > 0.05
+
+
+def test_lightmap_embed_empty_and_bad_arguments():
+    from tests import prepare_util as pu
+    gpu_init()
+    S = 32
+    dr = pu.embed_table(S, [77], tris_per_mesh=(20, 20), hard_cases=False)      # ids of the triangles name no page
+    pages = _embed_both(dr, 2, S)
+    assert all(not p[S * S * 20:].any() for p in pages)                          # nothing mapped: zeros, as Lightmap_New's calloc
+    api.lightmap_embed(dr, [], S)                                                 # no pages: nothing to do
+    import ctypes as C
+    lib = api.load_library()
+    arr = api._page_array(pages, S)
+    E_INVALID = -1                                                                # include/pimgpu.h
+    assert lib.pimgpu_lightmap_embed(None, None, arr, C.c_int32(2), C.c_int32(S)) == E_INVALID
+    assert lib.pimgpu_lightmap_embed(C.byref(dr.desc), None, arr, C.c_int32(2), C.c_int32(0)) == E_INVALID
+    assert lib.pimgpu_lightmap_embed(C.byref(dr.desc), None, None, C.c_int32(2), C.c_int32(S)) == E_INVALID
+    dr.mesh_ids[0] = 99
+    with pytest.raises(api.PimGpuError):
+        api.lightmap_embed(dr, pages, S)
+
+
+def test_lightmap_embed_feeds_the_bake():
+    """embed -> bake: the pages EmbedAttributes fills are LmPack_Bake's input (lightmap.c:1140-1152); the GPU chain
+    equals the oracle chain bit for bit"""
+    from tests import prepare_util as pu
+    from tests.util import OracleScene
+    sc = scenes.cornell_box()
+    S, tpm = 64, 2.0
+    dr, count = pu.world_mesh_with_charts(sc, S, tpm)
+    pg = _embed_both(dr, count, S, fill=0.0)
+    po = pu.oracle_embed(load_oracle(True), dr, pu.new_pages(count, S), S)
+    mapped = sum(int(pu.page_parts(p, S)[3].sum()) for p in pg)
+    assert mapped > 500
+    g = api.Scene(sc.desc); o = OracleScene(sc.desc, accel=1)
+    g.lightmap_bake(pg, S, tpm, 1.0, 2, passIndex=0, seed=5, maxBounces=3)
+    o.lightmap_bake(po, S, tpm, 1.0, 2, passIndex=0, seed=5, maxBounces=3)
+    for a, b in zip(pg, po):
+        assert_bits_equal(a, b, "baked page")
+    lit = sum(int((pu.page_parts(p, S)[0].reshape(5, S * S, 4)[:, :, :3].sum(axis=(0, 2)) > 0).sum()) for p in pg)
+    assert lit > 100
+    g.close()

@@ -88,3 +88,53 @@ def test_brdf_lut_statistics_and_progressive_blend():
     c = b.copy()
     lib.orc_brdf_lut_bake(c.ctypes.data, 32, 32, 256, 256, 7)
     assert np.array_equal(b, c)
+
+
+def test_embed_matches_the_pairwise_golden_function():
+    """orc_lightmap_embed (the reference's texel x drawable x triangle loop, lightmap.c:960-1031) against a
+    re-derivation from the per-pair function the golden vectors pin (lm_embed_fragment): nearest triangle below the
+    padding, the FIRST in drawable/vertex order on equal distance, probes untouched, unmapped drawables skipped"""
+    import ctypes as C
+    from tests import prepare_util as pu
+    lib = load_oracle()
+    S, ids = 24, [7, 3]
+    dr = pu.embed_table(S, ids, tris_per_mesh=(20, 30), chart_texels=(1.5, 6.0))
+    pages = pu.oracle_embed(lib, dr, pu.new_pages(2, S, fill=-3.0), S, page_tex_ids=ids, threads=3)
+    hook = lib.orc_hook_lm_embed_fragment
+    hook.restype = None
+    # the reference's candidate order: drawables in table order (sky flag, missing mesh, no texIndices skipped), triangles in vertex order
+    cands = []
+    for e, m in enumerate(dr.mesh_ids):
+        if m < 0 or dr.materials[e].flags & (2 | 16) or not dr.table[m].texIndices:
+            continue
+        arrays = dr.mesh_arrays[m]
+        for t in range(arrays[0].shape[0] // 3):
+            cands.append((arrays, t))
+    assert len(cands) == 20 + 30 + 20                                        # mesh 0 is drawn twice; entity 5 (mesh 1) is sky
+    inp = np.zeros(27, np.float32); out = np.zeros(8, np.uint32)
+    for page, tex_id in enumerate(ids):
+        probes, pos, nor, cnt = pu.page_parts(pages[page], S)
+        assert (probes == -3.0).all()
+        for texel in range(0, S * S, 5):
+            px = (texel % S + 0.5, texel // S + 0.5)
+            best = None
+            for (P, N, U, T), t in cands:
+                if T[t * 3, 3] != tex_id:
+                    continue
+                inp[0:6] = U[t * 3:t * 3 + 3, 2:].reshape(6); inp[6] = S; inp[7:9] = px
+                inp[9:18] = P[t * 3:t * 3 + 3, :3].reshape(9); inp[18:27] = N[t * 3:t * 3 + 3, :3].reshape(9)
+                hook(inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+                o = out.view(np.float32)
+                if o[0] < 2.0 and (best is None or o[0] < best[0]):
+                    best = o.copy()
+            if best is None:
+                assert cnt[texel] == 0.0 and not pos[texel].any() and not nor[texel].any()
+            else:
+                assert cnt[texel] == 1.0
+                np.testing.assert_array_equal(pos[texel], best[2:5]); np.testing.assert_array_equal(nor[texel], best[5:8])
+    # the zero-length edge of the hard cases has zero area: sdTriangle2D then calls every texel inside (negative
+    # distance), so its page is flooded -- the reference's behaviour, kept
+    assert max(pu.page_parts(p, S)[3].mean() for p in pages) == 1.0
+    plain = pu.oracle_embed(lib, pu.embed_table(S, ids, tris_per_mesh=(20, 30), chart_texels=(1.5, 6.0), hard_cases=False),
+                            pu.new_pages(2, S), S, page_tex_ids=ids)
+    assert all(0.05 < pu.page_parts(p, S)[3].mean() < 0.95 for p in plain)
