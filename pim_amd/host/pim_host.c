@@ -184,6 +184,34 @@ i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i
     return count;
 }
 
+void Lightmap_New(Lightmap* lm, i32 size)
+{
+    memset(lm, 0, sizeof(*lm));
+    if (size <= 0) return;
+    lm->size = size;
+    const size_t texelcount = (size_t)size * (size_t)size;
+    float* allocation = calloc(texelcount * 27, sizeof(float));      /* [5] float4 | float3 | float3 | float, lightmap.c:90-110 */
+    if (!allocation) { lm->size = 0; return; }
+    for (i32 i = 0; i < 5; ++i) lm->probes[i] = (float4*)(allocation + texelcount * 4 * (size_t)i);
+    lm->position = (float3*)(allocation + texelcount * 20);
+    lm->normal = (float3*)(allocation + texelcount * 23);
+    lm->sampleCounts = allocation + texelcount * 26;
+}
+
+void Lightmap_Del(Lightmap* lm)
+{
+    if (lm) { free(lm->probes[0]); memset(lm, 0, sizeof(*lm)); }
+}
+
+void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, const i32* texIds, i32 lmCount)
+{
+    if (!drawables || !lightmaps || lmCount <= 0) return;
+    PimLightmapPage* pages = calloc((size_t)lmCount, sizeof(PimLightmapPage));
+    for (i32 i = 0; i < lmCount; ++i) pages[i].block = &lightmaps[i].probes[0]->x;
+    ok(pimgpu_lightmap_embed(drawables, texIds, pages, lmCount, lightmaps[0].size), "LmPack_EmbedAttributes");
+    free(pages);
+}
+
 void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces)
 {
     if (!scene || !pack || pack->lmCount <= 0) return;

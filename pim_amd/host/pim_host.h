@@ -98,6 +98,14 @@ void PtResults_Del(PtResults* results);
 void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
 i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
 
+/* Lightmap_New / Lightmap_Del, rendering/lightmap.c:81-133: the single zeroed allocation per page (the Vulkan texture
+ * slot and upload are the renderer's); texId stands for Lightmap.slot.index (lightmap.h:30) */
+void Lightmap_New(Lightmap* lm, i32 size);
+void Lightmap_Del(Lightmap* lm);
+/* EmbedAttributes, rendering/lightmap.c:1034-1045, the last step of LmPack_Pack (:1092): fills position / normal /
+ * sampleCounts of every page from the draw table's uvs.zw and texIndices.w; texIds[lmCount] = the pages' texture ids
+ * (NULL: page i has id i) */
+void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, const i32* texIds, i32 lmCount);
 /* rendering/lightmap.c:1204-1223; pages must be the reference's single allocation per lightmap (probes[0] = base) */
 void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces);
 

@@ -133,3 +133,31 @@ def test_scene_producers_under_pim_names():
     host.PtScene_Del(scene)
     host.BrdfLut_Del(C.byref(lut))
     assert not lut.texels
+
+
+def test_lightmap_pages_under_pim_names():
+    """Lightmap_New (lightmap.c:81-110: one zeroed allocation, probes[0] its base) + EmbedAttributes (:1034-1045) through
+    the plain-C host layer: the same bits as the C-ABI call it wraps, probes left zero"""
+    from tests import prepare_util as pu
+    host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
+    host.PtSys_Init.restype = C.c_bool
+    assert host.PtSys_Init()
+
+    class Lightmap(C.Structure):
+        _fields_ = [("probes", C.POINTER(C.c_float) * 5), ("position", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)),
+                    ("sampleCounts", C.POINTER(C.c_float)), ("size", C.c_int32)]
+    S, ids = 48, [9, 4]
+    lms = (Lightmap * 2)()
+    for lm in lms:
+        host.Lightmap_New(C.byref(lm), C.c_int32(S))
+        assert lm.size == S and C.addressof(lm.position.contents) - C.addressof(lm.probes[0].contents) == S * S * 80
+        assert C.addressof(lm.sampleCounts.contents) - C.addressof(lm.probes[0].contents) == S * S * 104
+    dr = pu.embed_table(S, ids, tris_per_mesh=(80, 120), hard_cases=False)
+    tex = np.asarray(ids, np.int32)
+    host.LmPack_EmbedAttributes(C.byref(dr.desc), lms, tex.ctypes.data_as(C.c_void_p), C.c_int32(2))
+    want = api.lightmap_embed(dr, pu.new_pages(2, S), S, ids)
+    for lm, w in zip(lms, want):
+        got = np.ctypeslib.as_array(lm.probes[0], shape=(S * S * 27,))
+        assert (got.view(np.uint32) == w.view(np.uint32)).all() and got[S * S * 26:].sum() > 50
+        host.Lightmap_Del(C.byref(lm))
+        assert not lm.sampleCounts and lm.size == 0
