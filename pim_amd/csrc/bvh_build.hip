@@ -60,31 +60,45 @@ __global__ void k_bounds_init(uint32_t* bounds)
     else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
 }
 
+/* grid-stride: a block folds its triangles' centroids in registers, waves, then LDS, and ONE lane per block issues the six
+ * atomics (a single address sustains only ~90 atomics per microsecond: one set per wave made this kernel 4.3 ms of an
+ * 11 ms build at 4 M triangles, 21 ms at 20 M) */
 __global__ __launch_bounds__(256) void k_tri_bounds(const v4* __restrict__ positions, int32_t triCount,
     float4* __restrict__ triLo, float4* __restrict__ triHi, uint32_t* __restrict__ bounds)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float c[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
     float d[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    if (i < triCount)
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < triCount; i += gridDim.x * blockDim.x)
     {
         const v4 p0 = positions[i * 3 + 0], p1 = positions[i * 3 + 1], p2 = positions[i * 3 + 2];
         float lo[3] = { fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)) };
         float hi[3] = { fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)) };
+        float ctr[3];
         for (int a = 0; a < 3; ++a)
         {
-            c[a] = d[a] = 0.5f * (lo[a] + hi[a]);
+            ctr[a] = 0.5f * (lo[a] + hi[a]);
+            c[a] = fminf(c[a], ctr[a]); d[a] = fmaxf(d[a], ctr[a]);
             const float m = fmaxf(fmaxf(fabsf(lo[a]), fabsf(hi[a])), 1e-3f);
             const float pad = m * 4.0e-7f;          /* conservative against the rounding of the slab test */
             lo[a] -= pad; hi[a] += pad;
         }
-        triLo[i] = make_float4(lo[0], lo[1], lo[2], c[0]);
+        triLo[i] = make_float4(lo[0], lo[1], lo[2], ctr[0]);
         triHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
+    __shared__ float sh[6][4];
+    const int wave = threadIdx.x >> 6;
     for (int a = 0; a < 3; ++a)
     {
         const float mn = wave_min(c[a]), mx = wave_max(d[a]);
-        if ((threadIdx.x & 63) == 0 && mn <= mx)
+        if ((threadIdx.x & 63) == 0) { sh[a][wave] = mn; sh[3 + a][wave] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+    {
+        const int a = threadIdx.x;
+        const float mn = fminf(fminf(sh[a][0], sh[a][1]), fminf(sh[a][2], sh[a][3]));
+        const float mx = fmaxf(fmaxf(sh[3 + a][0], sh[3 + a][1]), fmaxf(sh[3 + a][2], sh[3 + a][3]));
+        if (mn <= mx)
         {
             atomicMin(&bounds[a], float_to_ordered(mn));
             atomicMax(&bounds[3 + a], float_to_ordered(mx));
@@ -373,103 +387,119 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn(const PlocState* __res
 
 __device__ __forceinline__ int32_t ploc_count_of(int32_t c, int32_t n, const int32_t* __restrict__ count) { return c >= n - 1 ? 1 : count[c]; }
 
-/* mutual pairs merge (the lower index keeps the new cluster, the higher one leaves the list); per-block survivor counts */
-__global__ __launch_bounds__(kPlocThreads) void k_ploc_merge(int32_t n, PlocState* __restrict__ state, const int32_t* __restrict__ nn,
-    int32_t* __restrict__ cid, float4* __restrict__ cLo, float4* __restrict__ cHi,
-    int32_t* __restrict__ child0, int32_t* __restrict__ child1, int32_t* __restrict__ parent,
-    float4* __restrict__ nodeLo, float4* __restrict__ nodeHi, int32_t* __restrict__ count,
-    uint8_t* __restrict__ keep, int32_t* __restrict__ blockCount)
+/*
+ * Mutual pairs merge: the lower index keeps the new cluster, the higher one leaves the list.  Three launches per round and
+ * no atomics (node ids taken with one returning atomic per wave on a single counter cost 2 of the 3 ms the rounds took at
+ * 4 M triangles; a single address sustains ~90 per microsecond): k_ploc_merge marks survivors and merging lanes and counts
+ * both per block, k_ploc_scan turns the counts into list positions and node ids, k_ploc_scatter makes the nodes and
+ * writes the next list.  Node numbering is deterministic this way.
+ */
+#define PLOC_KEPT   1
+#define PLOC_MERGES 2
+
+__global__ __launch_bounds__(kPlocThreads) void k_ploc_merge(const PlocState* __restrict__ state, const int32_t* __restrict__ nn,
+    uint8_t* __restrict__ keep, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount)
 {
     const int32_t m = state->m;
     const int32_t base = blockIdx.x * kPlocThreads;
-    if (base >= m) { if (threadIdx.x == 0) blockCount[blockIdx.x] = 0; return; }
+    if (base >= m) { if (threadIdx.x == 0) { blockCount[blockIdx.x] = 0; mergeCount[blockIdx.x] = 0; } return; }
     const int32_t i = base + (int32_t)threadIdx.x;
     bool kept = false, merges = false;
-    int32_t j = -1;
     if (i < m)
     {
-        j = nn[i];
+        const int32_t j = nn[i];
         const bool mutual = j >= 0 && nn[j] == i;
         kept = !(mutual && j < i);
         merges = mutual && i < j;
+        keep[i] = (kept ? PLOC_KEPT : 0) | (merges ? PLOC_MERGES : 0);
     }
-    /* node ids: one atomic per wave */
-    const uint64_t mm = __ballot(merges);
-    int32_t id0 = 0;
+    __shared__ int32_t sCnt[2][kPlocThreads / 64];
     const int lane = threadIdx.x & 63;
-    if (mm)
-    {
-        const int leader = __ffsll((long long)mm) - 1;
-        if (lane == leader) id0 = atomicAdd(&state->nodeCounter, (int32_t)__popcll(mm));
-        id0 = __shfl(id0, leader, 64);
-    }
-    if (merges)
-    {
-        const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int32_t id = id0 + (int32_t)__popcll(mm & lt);
-        const int32_t a = cid[i], b = cid[j];
-        const float4 alo = cLo[i], ahi = cHi[i], blo = cLo[j], bhi = cHi[j];
-        const float4 lo = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.0f);
-        const float4 hi = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.0f);
-        child0[id] = a; child1[id] = b;
-        parent[a] = id; parent[b] = id;
-        nodeLo[id] = lo; nodeHi[id] = hi;
-        count[id] = ploc_count_of(a, n, count) + ploc_count_of(b, n, count);
-        cid[i] = id; cLo[i] = lo; cHi[i] = hi;           /* in place: nobody else reads entry i in this kernel */
-    }
-    if (i < m) keep[i] = kept ? 1 : 0;
-    __shared__ int32_t sCnt[kPlocThreads / 64];
-    const uint64_t km = __ballot(kept);
-    if (lane == 0) sCnt[threadIdx.x >> 6] = (int32_t)__popcll(km);
-    __syncthreads();
-    if (threadIdx.x == 0) { int32_t t = 0; for (int w = 0; w < kPlocThreads / 64; ++w) t += sCnt[w]; blockCount[blockIdx.x] = t; }
-}
-
-/* exclusive scan of the per-block survivor counts (one workgroup), new list length */
-__global__ __launch_bounds__(256) void k_ploc_scan(PlocState* __restrict__ state, int32_t* __restrict__ blockCount, int32_t numBlocks)
-{
-    __shared__ int32_t part[256];
-    const int32_t m = state->m;
-    const int32_t used = (m + kPlocThreads - 1) / kPlocThreads < numBlocks ? (m + kPlocThreads - 1) / kPlocThreads : numBlocks;
-    const int32_t per = (used + 255) / 256;
-    const int32_t b0 = min((int32_t)threadIdx.x * per, used), b1 = min(b0 + per, used);
-    int32_t s = 0;
-    for (int32_t b = b0; b < b1; ++b) s += blockCount[b];
-    part[threadIdx.x] = s;
+    const uint64_t km = __ballot(kept), mm = __ballot(merges);
+    if (lane == 0) { sCnt[0][threadIdx.x >> 6] = (int32_t)__popcll(km); sCnt[1][threadIdx.x >> 6] = (int32_t)__popcll(mm); }
     __syncthreads();
     if (threadIdx.x == 0)
     {
-        int32_t run = 0;
-        for (int i = 0; i < 256; ++i) { const int32_t v = part[i]; part[i] = run; run += v; }
-        state->mPrev = m; state->m = run;
+        int32_t t = 0, u = 0;
+        for (int w = 0; w < kPlocThreads / 64; ++w) { t += sCnt[0][w]; u += sCnt[1][w]; }
+        blockCount[blockIdx.x] = t; mergeCount[blockIdx.x] = u;
     }
-    __syncthreads();
-    int32_t run = part[threadIdx.x];
-    for (int32_t b = b0; b < b1; ++b) { const int32_t v = blockCount[b]; blockCount[b] = run; run += v; }
 }
 
-/* survivors move to the other list, order kept */
-__global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter(const PlocState* __restrict__ state, const uint8_t* __restrict__ keep,
-    const int32_t* __restrict__ blockOffset, const int32_t* __restrict__ cidIn, const float4* __restrict__ cLoIn, const float4* __restrict__ cHiIn,
-    int32_t* __restrict__ cidOut, float4* __restrict__ cLoOut, float4* __restrict__ cHiOut)
+/* exclusive scans of the per-block survivor and merge counts (one workgroup): new list length, first node id of each block */
+__global__ __launch_bounds__(256) void k_ploc_scan(PlocState* __restrict__ state, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount,
+    int32_t numBlocks)
+{
+    __shared__ int32_t part[2][256];
+    const int32_t m = state->m;
+    const int32_t nodeBase = state->nodeCounter;
+    const int32_t used = (m + kPlocThreads - 1) / kPlocThreads < numBlocks ? (m + kPlocThreads - 1) / kPlocThreads : numBlocks;
+    const int32_t per = (used + 255) / 256;
+    const int32_t b0 = min((int32_t)threadIdx.x * per, used), b1 = min(b0 + per, used);
+    int32_t s = 0, t = 0;
+    for (int32_t b = b0; b < b1; ++b) { s += blockCount[b]; t += mergeCount[b]; }
+    part[0][threadIdx.x] = s; part[1][threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int32_t run = 0, ids = nodeBase;
+        for (int i = 0; i < 256; ++i)
+        {
+            const int32_t v = part[0][i]; part[0][i] = run; run += v;
+            const int32_t u = part[1][i]; part[1][i] = ids; ids += u;
+        }
+        state->mPrev = m; state->m = run; state->nodeCounter = ids;
+    }
+    __syncthreads();
+    int32_t run = part[0][threadIdx.x], ids = part[1][threadIdx.x];
+    for (int32_t b = b0; b < b1; ++b)
+    {
+        const int32_t v = blockCount[b]; blockCount[b] = run; run += v;
+        const int32_t u = mergeCount[b]; mergeCount[b] = ids; ids += u;
+    }
+}
+
+/* survivors move to the other list, order kept; a merging survivor becomes the new node */
+__global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter(int32_t n, const PlocState* __restrict__ state, const uint8_t* __restrict__ keep,
+    const int32_t* __restrict__ nn, const int32_t* __restrict__ blockOffset, const int32_t* __restrict__ mergeOffset,
+    const int32_t* __restrict__ cidIn, const float4* __restrict__ cLoIn, const float4* __restrict__ cHiIn,
+    int32_t* __restrict__ cidOut, float4* __restrict__ cLoOut, float4* __restrict__ cHiOut,
+    int32_t* __restrict__ child0, int32_t* __restrict__ child1, int32_t* __restrict__ parent,
+    float4* __restrict__ nodeLo, float4* __restrict__ nodeHi, int32_t* __restrict__ count)
 {
     const int32_t m = state->mPrev;
     const int32_t base = blockIdx.x * kPlocThreads;
     if (base >= m) return;
     const int32_t i = base + (int32_t)threadIdx.x;
-    const bool kept = i < m && keep[i] != 0;
-    __shared__ int32_t sCnt[kPlocThreads / 64];
+    const uint8_t f = i < m ? keep[i] : 0;
+    const bool kept = (f & PLOC_KEPT) != 0, merges = (f & PLOC_MERGES) != 0;
+    __shared__ int32_t sCnt[2][kPlocThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t km = __ballot(kept);
-    if (lane == 0) sCnt[wave] = (int32_t)__popcll(km);
+    const uint64_t km = __ballot(kept), mm = __ballot(merges);
+    if (lane == 0) { sCnt[0][wave] = (int32_t)__popcll(km); sCnt[1][wave] = (int32_t)__popcll(mm); }
     __syncthreads();
-    int32_t off = blockOffset[blockIdx.x];
-    for (int w = 0; w < wave; ++w) off += sCnt[w];
+    int32_t off = blockOffset[blockIdx.x], ids = mergeOffset[blockIdx.x];
+    for (int w = 0; w < wave; ++w) { off += sCnt[0][w]; ids += sCnt[1][w]; }
     if (kept)
     {
         const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int32_t dst = off + (int32_t)__popcll(km & lt);
-        cidOut[dst] = cidIn[i]; cLoOut[dst] = cLoIn[i]; cHiOut[dst] = cHiIn[i];
+        int32_t id = cidIn[i];
+        float4 lo = cLoIn[i], hi = cHiIn[i];
+        if (merges)
+        {
+            const int32_t j = nn[i];
+            const int32_t a = id, b = cidIn[j];
+            const float4 blo = cLoIn[j], bhi = cHiIn[j];
+            lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), 0.0f);
+            hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
+            id = ids + (int32_t)__popcll(mm & lt);
+            child0[id] = a; child1[id] = b;
+            parent[a] = id; parent[b] = id;
+            nodeLo[id] = lo; nodeHi[id] = hi;
+            count[id] = ploc_count_of(a, n, count) + ploc_count_of(b, n, count);
+        }
+        cidOut[dst] = id; cLoOut[dst] = lo; cHiOut[dst] = hi;
     }
 }
 
@@ -670,15 +700,23 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
             }
         }
     }
-    /* allocate the wide children of the whole wave with one atomic */
+    /* allocate the wide children of the whole block with one atomic (a single counter sustains ~90 per microsecond) */
     int need = 0;
     for (int k = 0; k < ns; ++k) need += (cd[k].count > PT_LEAF_MAX) ? 1 : 0;
     int incl = need;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
-    const int total = __shfl(incl, 63, 64);
-    int32_t base = 0;
-    if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(nodeCounter, total);
-    base = __shfl(base, 63, 64);
+    __shared__ int32_t sTot[4], sBase;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) sTot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int total = sTot[0] + sTot[1] + sTot[2] + sTot[3];
+        sBase = total > 0 ? atomicAdd(nodeCounter, total) : 0;
+    }
+    __syncthreads();
+    int32_t base = sBase;
+    for (int k = 0; k < wave; ++k) base += sTot[k];
     if (!active) return;
     int32_t next = base + incl - need;
     WideSlot slot[4];
@@ -847,7 +885,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     const int32_t plocBlocks = (cap + kPlocThreads - 1) / kPlocThreads;
     const size_t oCidA = take(4 * (size_t)cap), oCidB = take(4 * (size_t)cap);
     const size_t oCLoA = take(sizeof(float4) * cap), oCHiA = take(sizeof(float4) * cap), oCLoB = take(sizeof(float4) * cap), oCHiB = take(sizeof(float4) * cap);
-    const size_t oNn = take(4 * (size_t)cap), oKeep = take((size_t)cap), oBlockCount = take(4 * (size_t)plocBlocks + 4);
+    const size_t oNn = take(4 * (size_t)cap), oKeep = take((size_t)cap), oBlockCount = take(4 * (size_t)plocBlocks + 4), oMergeCount = take(4 * (size_t)plocBlocks + 4);
     const size_t oCount = take(4 * (size_t)cap), oNewPos = take(4 * (size_t)cap), oVals2 = take(4 * (size_t)cap), oPloc = take(64);
     const size_t need = off;
     if (b->capacityTris < cap || b->scratchBytes < need)
@@ -872,7 +910,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     int32_t* snap = (int32_t*)(s + oSnap); int32_t* nodeCounter = snap + kMaxWideLevels + 4;
     int32_t* cidA = (int32_t*)(s + oCidA); int32_t* cidB = (int32_t*)(s + oCidB);
     float4* cLoA = (float4*)(s + oCLoA); float4* cHiA = (float4*)(s + oCHiA); float4* cLoB = (float4*)(s + oCLoB); float4* cHiB = (float4*)(s + oCHiB);
-    int32_t* nn = (int32_t*)(s + oNn); uint8_t* keep = (uint8_t*)(s + oKeep); int32_t* blockCount = (int32_t*)(s + oBlockCount);
+    int32_t* nn = (int32_t*)(s + oNn); uint8_t* keep = (uint8_t*)(s + oKeep); int32_t* blockCount = (int32_t*)(s + oBlockCount); int32_t* mergeCount = (int32_t*)(s + oMergeCount);
     int32_t* count = (int32_t*)(s + oCount); int32_t* newPos = (int32_t*)(s + oNewPos); uint32_t* vals2 = (uint32_t*)(s + oVals2);
     PlocState* ploc = (PlocState*)(s + oPloc);
 
@@ -881,7 +919,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     b->depth = 0;
     const int grid = (cap + 255) / 256;
     k_bounds_init<<<1, 64, 0, stream>>>(bounds);
-    if (n > 0) k_tri_bounds<<<grid, 256, 0, stream>>>(positionsDev, n, triLo, triHi, bounds);
+    if (n > 0) k_tri_bounds<<<std::min(grid, 2048), 256, 0, stream>>>(positionsDev, n, triLo, triHi, bounds);
     if (n <= PT_LEAF_MAX)
     {
         k_emit_single<<<1, 64, 0, stream>>>(n, triLo, triHi, b->nodes);
@@ -920,9 +958,10 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             if (++rounds > 4096) { set_error("BVH build: clustering does not converge"); return PIMGPU_E_STATE; }
             const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
             k_ploc_nn<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, nn);
-            k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(n, ploc, nn, cidIn, loIn, hiIn, child0, child1, parent, nodeLo, nodeHi, count, keep, blockCount);
-            k_ploc_scan<<<1, 256, 0, stream>>>(ploc, blockCount, nb);
-            k_ploc_scatter<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, blockCount, cidIn, loIn, hiIn, cidOut, loOut, hiOut);
+            k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, nn, keep, blockCount, mergeCount);
+            k_ploc_scan<<<1, 256, 0, stream>>>(ploc, blockCount, mergeCount, nb);
+            k_ploc_scatter<<<nb, kPlocThreads, 0, stream>>>(n, ploc, keep, nn, blockCount, mergeCount, cidIn, loIn, hiIn, cidOut, loOut, hiOut,
+                child0, child1, parent, nodeLo, nodeHi, count);
             std::swap(cidIn, cidOut); std::swap(loIn, loOut); std::swap(hiIn, hiOut);
             if ((rounds & 3) == 0)
             {
