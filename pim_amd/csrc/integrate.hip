@@ -765,11 +765,11 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
  * this covers maxBounces == 0 style early stops): not needed -- shade_b finishes every path at the limit. */
 
 /* TraceFn's accumulate, pt.c:2547-2552 */
-__global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restrict__ results, int32_t n, float sampleWeight,
+__global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restrict__ results, int32_t width, int32_t height, float sampleWeight,
     float* __restrict__ color, float* __restrict__ albedo, float* __restrict__ normal)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= width * height) return;
     const PimResult r = results[i];
     for (int k = 0; k < 3; ++k)
     {
@@ -982,7 +982,8 @@ int integrate_paths(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
  */
 static constexpr int kDefaultGroups = 1, kDefaultStagger = 2, kDefaultGroupMinPaths = 1 << 18;
 
-int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut)
+template <class Epilogue>
+int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStats* statsOut, float* traceMsOut, Epilogue&& epilogue)
 {
     /* read per call: the tests sweep them */
     const int kImageGroups = std::max(1, std::min(kMaxGroups, env_int("PIMGPU_GROUPS", kDefaultGroups)));
@@ -990,12 +991,20 @@ int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
     const int kGroupMinPaths = std::max(64, env_int("PIMGPU_GROUP_MIN_PATHS", kDefaultGroupMinPaths));
     int groups = (int)std::min<int64_t>(kImageGroups, std::max<int64_t>(1, n / kGroupMinPaths));
     if (g_lib.trace.counting) groups = 1;           /* the work counters live in the main stream's resources */
-    if (groups <= 1) return integrate_paths(scene, n, maxBounces, statsOut, traceMsOut);
     int rc = PIMGPU_OK;
     for (int gi = 0; gi < groups; ++gi) if ((rc = g_lib.ensure_group(gi))) return rc;
     const bool timeTrace = traceMsOut != nullptr && !getenv("PIMGPU_NO_EVENTS");
     if (traceMsOut) *traceMsOut = 0.0f;
     hipStream_t main = g_lib.stream;
+    if (groups <= 1)
+    {
+        /* the epilogue (the image resolve) is enqueued BEFORE the host waits for the statistics: no idle gap between the
+         * last integrator launch and it (80 us of a 2.4 ms Cornell sample when it came after the wait) */
+        PathGroup& g = g_lib.groups[0];
+        if ((rc = integrate_enqueue(scene, g, 0, n, maxBounces, timeTrace, -1))) { hipStreamSynchronize(g.stream); return rc; }
+        epilogue(main);
+        return integrate_finish(g, statsOut, traceMsOut);
+    }
     /* what the main stream has enqueued so far (path set-up) comes first for every share */
     hipEvent_t start = g_lib.groups[0].done;
     PT_HIP(hipEventRecord(start, main));
@@ -1012,8 +1021,10 @@ int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
             if (kGroupStagger >= 0) PT_HIP(hipStreamWaitEvent(g.stream, g_lib.groups[gi - 1].stagger, 0));
         }
         rc = integrate_enqueue(scene, g, first, count, maxBounces, timeTrace, kGroupStagger);
+        if (gi > 0) { PT_HIP(hipEventRecord(g.done, g.stream)); PT_HIP(hipStreamWaitEvent(main, g.done, 0)); }
         ++used;
     }
+    if (rc == PIMGPU_OK) epilogue(main);             /* after every share: the main stream has waited for the others */
     for (int gi = used - 1; gi >= 0; --gi)
     {
         const int r = integrate_finish(g_lib.groups[gi], statsOut, traceMsOut);
@@ -1112,9 +1123,8 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
-    if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr))) return rc;
-    k_resolve_image<<<(n + 255) / 256, 256, 0, st>>>(w.results, n, p->sampleWeight, t->color, t->albedo, t->normal);
-    PT_HIP(hipEventRecord(e1, st));
+    if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr, [&](hipStream_t s)
+        { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, t->width, t->height, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s); }))) return rc;
     PT_HIP(hipEventSynchronize(e1));
     float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
