@@ -427,36 +427,42 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_merge(const PlocState* __
 }
 
 /* exclusive scans of the per-block survivor and merge counts (one workgroup): new list length, first node id of each block */
-__global__ __launch_bounds__(256) void k_ploc_scan(PlocState* __restrict__ state, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount,
+static constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t* sWave, int32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    int32_t base = 0, all = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) { const int32_t t = sWave[w]; if (w < wave) base += t; all += t; }
+    __syncthreads();
+    *total = all;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_ploc_scan(PlocState* __restrict__ state, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount,
     int32_t numBlocks)
 {
-    __shared__ int32_t part[2][256];
+    __shared__ int32_t sWave[kScanThreads / 64];
     const int32_t m = state->m;
     const int32_t nodeBase = state->nodeCounter;
     const int32_t used = (m + kPlocThreads - 1) / kPlocThreads < numBlocks ? (m + kPlocThreads - 1) / kPlocThreads : numBlocks;
-    const int32_t per = (used + 255) / 256;
+    const int32_t per = (used + kScanThreads - 1) / kScanThreads;
     const int32_t b0 = min((int32_t)threadIdx.x * per, used), b1 = min(b0 + per, used);
     int32_t s = 0, t = 0;
     for (int32_t b = b0; b < b1; ++b) { s += blockCount[b]; t += mergeCount[b]; }
-    part[0][threadIdx.x] = s; part[1][threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        int32_t run = 0, ids = nodeBase;
-        for (int i = 0; i < 256; ++i)
-        {
-            const int32_t v = part[0][i]; part[0][i] = run; run += v;
-            const int32_t u = part[1][i]; part[1][i] = ids; ids += u;
-        }
-        state->mPrev = m; state->m = run; state->nodeCounter = ids;
-    }
-    __syncthreads();
-    int32_t run = part[0][threadIdx.x], ids = part[1][threadIdx.x];
+    int32_t kept = 0, merged = 0;
+    int32_t run = block_exclusive_scan(s, sWave, &kept);
+    int32_t ids = nodeBase + block_exclusive_scan(t, sWave, &merged);
     for (int32_t b = b0; b < b1; ++b)
     {
         const int32_t v = blockCount[b]; blockCount[b] = run; run += v;
         const int32_t u = mergeCount[b]; mergeCount[b] = ids; ids += u;
     }
+    if (threadIdx.x == 0) { state->mPrev = m; state->m = kept; state->nodeCounter = nodeBase + merged; }
 }
 
 /* survivors move to the other list, order kept; a merging survivor becomes the new node */
@@ -583,19 +589,42 @@ __device__ __forceinline__ int32_t ploc_offset_of(int32_t c, int32_t n, const in
     return off;
 }
 
-__global__ __launch_bounds__(256) void k_ploc_order(int32_t n, const uint32_t* __restrict__ vals,
+/*
+ * Place of every subtree's leaves in the tree order, in three launches instead of one walk to the root per node (2 n walks
+ * of ~50 dependent loads were 3.4 ms of a 15.5 ms build at 20 M triangles): (0) the few nodes with at least kOrderBig
+ * leaves walk to the root; (1) the other inner nodes walk only up to their first such ancestor; (2) a leaf takes one step
+ * from its parent.
+ */
+static constexpr int32_t kOrderBig = 64;
+
+__global__ __launch_bounds__(256) void k_ploc_order(int32_t phase, int32_t n, const uint32_t* __restrict__ vals,
     const int32_t* __restrict__ child0, const int32_t* __restrict__ child1, const int32_t* __restrict__ parent, const int32_t* __restrict__ count,
     int32_t* __restrict__ rangeFirst, int32_t* __restrict__ rangeLast, int32_t* __restrict__ newPos, uint32_t* __restrict__ valsOut)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n - 1)
+    if (phase == 0)
     {
+        if (i >= n - 1 || count[i] < kOrderBig) return;
         const int32_t off = ploc_offset_of(i, n, child0, child1, parent, count);
         rangeFirst[i] = off; rangeLast[i] = off + count[i] - 1;
     }
-    if (i < n)
+    else if (phase == 1)
     {
-        const int32_t off = ploc_offset_of((n - 1) + i, n, child0, child1, parent, count);
+        if (i >= n - 1 || count[i] >= kOrderBig) return;
+        int32_t off = 0, c = i, p = parent[c];
+        for (; p >= 0; c = p, p = parent[p])
+        {
+            if (child1[p] == c) off += ploc_count_of(child0[p], n, count);
+            if (count[p] >= kOrderBig) { off += rangeFirst[p]; break; }
+        }
+        rangeFirst[i] = off; rangeLast[i] = off + count[i] - 1;
+    }
+    else
+    {
+        if (i >= n) return;
+        const int32_t c = (n - 1) + i, p = parent[c];
+        int32_t off = 0;
+        if (p >= 0) off = rangeFirst[p] + ((child1[p] == c) ? ploc_count_of(child0[p], n, count) : 0);
         newPos[i] = off; valsOut[off] = vals[i];
     }
 }
@@ -959,7 +988,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
             k_ploc_nn<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, nn);
             k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, nn, keep, blockCount, mergeCount);
-            k_ploc_scan<<<1, 256, 0, stream>>>(ploc, blockCount, mergeCount, nb);
+            k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
             k_ploc_scatter<<<nb, kPlocThreads, 0, stream>>>(n, ploc, keep, nn, blockCount, mergeCount, cidIn, loIn, hiIn, cidOut, loOut, hiOut,
                 child0, child1, parent, nodeLo, nodeHi, count);
             std::swap(cidIn, cidOut); std::swap(loIn, loOut); std::swap(hiIn, hiOut);
@@ -973,7 +1002,8 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             }
         }
         k_ploc_finish<<<1, kPlocFinish, 0, stream>>>(n, ploc, cidIn, loIn, hiIn, child0, child1, parent, nodeLo, nodeHi, count);
-        k_ploc_order<<<grid, 256, 0, stream>>>(n, vin, child0, child1, parent, count, rangeFirst, rangeLast, newPos, vals2);
+        for (int phase = 0; phase < 3; ++phase)
+            k_ploc_order<<<grid, 256, 0, stream>>>(phase, n, vin, child0, child1, parent, count, rangeFirst, rangeLast, newPos, vals2);
         k_ploc_remap<<<grid, 256, 0, stream>>>(n, newPos, child0, child1);
         order = vals2;
         rootId = &ploc->rootId;
