@@ -313,7 +313,7 @@ int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
         s->d.cellLength = s->cellLength; s->d.pdf = s->pdf; s->d.cdf = s->cdf; s->d.live = s->live;
         s->d.cellSum = s->cellSum; s->d.cellIntegral = s->cellIntegral;
         PT_HIP(hipEventRecord(e0, g_lib.stream));
-        rc = setup_light_grid(s->d, s->metersPerCell, s->seed, s->cellLength, g_lib.trace.status, g_lib.stream);
+        rc = setup_light_grid(s->d, &g_lib.trace, s->metersPerCell, s->seed, s->cellLength, g_lib.stream);
         PT_HIP(hipEventRecord(e1, g_lib.stream));
         if (rc) return fail(rc);
         PT_HIP(hipStreamSynchronize(g_lib.stream));

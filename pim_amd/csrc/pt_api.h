@@ -111,7 +111,7 @@ int check_ready();
 
 /* setup.hip */
 int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float* pdfsDev, hipStream_t stream);
-int setup_light_grid(const DScene& s, float metersPerCell, uint32_t seed, int32_t* cellLengthDev, uint32_t* statusDev, hipStream_t stream);
+int setup_light_grid(const DScene& s, TraceResources* res, float metersPerCell, uint32_t seed, int32_t* cellLengthDev, hipStream_t stream);
 int update_dists(const DScene& s, hipStream_t stream);
 
 /* integrate.hip */
