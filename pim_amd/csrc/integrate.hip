@@ -916,15 +916,15 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
             break;
         }
         ++g.wavefrontBounces;
-        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
-        if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st))) break;
-        if (timeTrace) { hipEventRecord(t1, st); g.events.push_back({ t0, t1 }); }
+        t0 = t1 = nullptr;
+        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); g.events.push_back({ t0, t1 }); }
+        if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st, t0, t1))) break;
         k_shade_a<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_a<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         half_done();
-        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); hipEventRecord(t0, st); }
-        if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st))) break;
-        if (timeTrace) { hipEventRecord(t1, st); g.events.push_back({ t0, t1 }); }
+        t0 = t1 = nullptr;
+        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); g.events.push_back({ t0, t1 }); }
+        if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st, t0, t1))) break;
         k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         half_done();

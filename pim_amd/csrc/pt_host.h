@@ -45,7 +45,7 @@ struct TraceResources
 
 /* trace.hip */
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
-    int32_t n, const int32_t* countDev, hipStream_t stream);
+    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, int32_t* occluded,
     int32_t n, hipStream_t stream);
 int make_rayhits(const DScene& scene, const float4* rayD, const DHit* hits, PimRayHit* out, int32_t n, hipStream_t stream);

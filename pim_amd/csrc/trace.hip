@@ -9,6 +9,7 @@
  */
 #include "pt_host.h"
 #include "traverse.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <algorithm>
 
@@ -266,13 +267,24 @@ void TraceResources::release()
     spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
+/* t0 / t1 (optional): events attached to the dispatch itself (hipExtLaunchKernelGGL): they time the kernel from its own
+ * completion signal.  Separate hipEventRecord calls around the launch put two barrier packets into the queue, ~6 us of
+ * idle GPU each -- 12 per Cornell sample. */
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
-    int32_t n, const int32_t* countDev, hipStream_t stream)
+    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0, hipEvent_t t1)
 {
     if (n <= 0) return PIMGPU_OK;
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
-    if (res->counting) k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
+    int32_t* noOccluded = nullptr;
+    if (res->counting)
+    {
+        if (t0) hipEventRecord(t0, stream);
+        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
+        if (t1) hipEventRecord(t1, stream);
+    }
+    else if (t0 && t1) hipExtLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
+        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work);
     else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
