@@ -797,23 +797,39 @@ __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ 
     }
 }
 
+/* One wave.  The serial chain sum += term[k] is kept (its order is the result), but the running sum TRAVELS across the lanes
+ * instead of the terms travelling to one lane: every lane holds one term of the current 64, and one DPP add per term,
+ * acc[k] = acc[k - 1 (rotating)] + term[k], moves the true running sum from lane k - 1 to lane k (the other lanes compute
+ * values nobody reads).  After 64 adds it sits in lane 63 and rotates into lane 0 for the next 64 terms.  One dependent
+ * VALU instruction per term, no LDS, no cross-lane reads. */
 __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
 {
-    constexpr int kTile = 2048;
-    __shared__ float tile[kTile];
-    float sum = 0.0f;
-    for (int32_t base = 0; base < len; base += kTile)
+    constexpr int kWaveRor1 = 0x13C;                /* DPP control: wave rotate right by one lane (GFX9) */
+    const int lane = threadIdx.x;
+    float acc = 0.0f;
+    float next = lane < len ? terms[lane] : 0.0f;
+    int32_t last = 0;                               /* lane that holds the total at the end */
+    for (int32_t base = 0; base < len; base += 64)
     {
-        for (int k = threadIdx.x; k < kTile; k += 64) tile[k] = (base + k < len) ? terms[base + k] : 0.0f;
-        __syncthreads();
-        if (threadIdx.x == 0)
+        const float v = next;
+        const int32_t ahead = base + 64 + lane;
+        next = ahead < len ? terms[ahead] : 0.0f;
+        const int32_t m = min(64, len - base);
+        if (m == 64)
         {
-            const int32_t m = min(kTile, len - base);
-            for (int32_t k = 0; k < m; ++k) sum += tile[k];
+#pragma unroll
+            for (int k = 0; k < 64; ++k)
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), kWaveRor1, 0xf, 0xf, false)) + v;
         }
-        __syncthreads();
+        else
+        {
+            for (int k = 0; k < m; ++k)
+                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), kWaveRor1, 0xf, 0xf, false)) + v;
+        }
+        last = m - 1;
     }
-    if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(sum) : sum;
+    const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), last));
+    if (lane == 0) out[0] = sqrtOut ? pt_sqrt(sum) : sum;
 }
 
 /* ---------------------------------------------------------------------------------------------- */
