@@ -129,6 +129,7 @@ struct StageArgs
     int32_t bounce, bounceLimit;
     int32_t* slowA; int32_t* slowB; /* queue positions the FAST builds deferred (lengths: counters[2], counters[3]) */
     int32_t tailLanes;              /* k_tail: lanes of each wave that take paths */
+    unsigned long long* spill;      /* k_tail: overflow area of the traversal stacks (TraceResources::spill) */
 };
 
 __device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
@@ -730,6 +731,17 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
     bool have = false;
     int32_t slot = 0, b = 0;
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o;
+#ifdef PT_TAIL_TRIVIAL_STACK
+    TrivialStack st;
+#else
+    /* the traversal stack of the two rays of a bounce: LDS (lane-interleaved) + spill area, as in k_trace -- a pop from
+     * a private-memory stack is a memory round trip on the path's dependent chain */
+    __shared__ unsigned long long sStack[PT_STACK_LDS * kTailThreads];
+    LdsStack st;
+    st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = kTailThreads;
+    st.spillStride = (int64_t)gridDim.x * kTailThreads;
+    st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * kTailThreads + threadIdx.x));
+#endif
     for (;;)
     {
         if ((int32_t)(threadIdx.x & 63) >= a.tailLanes) break;
@@ -739,7 +751,6 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
             if (pos >= count) break;
             slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true;
         }
-        TrivialStack st;
         const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
         ++ext;
         const StageAOut ra = stage_a<true>(s, a, slot, eh, b);
@@ -917,7 +928,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         a.extO = w.extO[in] + first; a.extD = w.extD[in] + first; a.extHit = w.extHit + first; a.neeHit = w.neeHit + first;
         a.neeO = w.neeO + first; a.neeD = w.neeD + first;
         a.extOOut = w.extO[out] + first; a.extDOut = w.extD[out] + first; a.results = w.results; a.stats = g.stats;
-        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64;
+        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = nullptr;
         if (b >= tailBounce)
         {
             /* the queue is short by now (or the caller forced it): one launch finishes every path.
@@ -926,7 +937,9 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
             const int64_t expect = (g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n;
             a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
             const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * kTailWavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
-            const int tailBlocks = (int)std::max<int64_t>(1, want);
+            if ((rc = g.trace->ensure())) break;
+            a.spill = g.trace->spill;                   /* sized for gridBlocks * 256 lanes */
+            const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
             k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
