@@ -352,10 +352,11 @@ __global__ __launch_bounds__(64) void k_ambcube_fit(const PimResult* __restrict_
 struct StageAOut { float4 nO, nD; bool deferred; uint32_t shadow, other; bool overflow; };
 
 template <bool SLOW>
-__device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a, int32_t slot, const DHit extHit, int32_t bounce)
+__device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a, int32_t slot, const DHit extHit, int32_t bounce, const LdsStack& stack)
 {
         StageAOut out; out.deferred = false; out.shadow = 0; out.other = 0; out.overflow = false;
         Ctx ctx = ctx_make();
+        if (SLOW) ctx.stack = stack;
         { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
         const v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
         v4 attenuation = ld4(a.ps.atten, slot);
@@ -484,9 +485,22 @@ __device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a
         return out;
 }
 
+/* the traversal stack of a kernel's inline rays: lane-interleaved LDS words + the spill area behind them (traverse.h) */
+__device__ __forceinline__ LdsStack kernel_stack(unsigned long long* shared, const StageArgs& a)
+{
+    LdsStack st;
+    st.lds = (lds_u64*)(shared + threadIdx.x); st.ldsStride = (int)blockDim.x;
+    st.spillStride = (int64_t)gridDim.x * blockDim.x;
+    st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x));
+    st.sp = 0;
+    return st;
+}
+
 template <bool SLOW>
 __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_a(DScene s, StageArgs a)
 {
+    __shared__ unsigned long long sStack[SLOW ? PT_STACK_LDS * kShadeThreads : 1];
+    const LdsStack stack = kernel_stack(sStack, a);
     const int32_t count = SLOW ? a.counters[2] : a.counters[a.inSel];
     if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0)
     {
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         if (idx < count)
         {
             pos = SLOW ? a.slowA[idx] : idx;
-            const StageAOut r = stage_a<SLOW>(s, a, a.queueIn[pos], a.extHit[pos], a.bounce);
+            const StageAOut r = stage_a<SLOW>(s, a, a.queueIn[pos], a.extHit[pos], a.bounce, stack);
             a.neeO[pos] = r.nO; a.neeD[pos] = r.nD;
             deferred = r.deferred;
             shadow += r.shadow; other += r.other; overflow |= r.overflow;
@@ -531,7 +545,7 @@ struct StageBOut { bool alive, deferred; v4 ro, rd; uint32_t other; bool overflo
 
 template <bool SLOW>
 __device__ __forceinline__ StageBOut stage_b(const DScene& s, const StageArgs& a, int32_t slot, const DHit extHit, const float4 neeD,
-    const DHit neeHit, int32_t bounce)
+    const DHit neeHit, int32_t bounce, const LdsStack& stack)
 {
             StageBOut out; out.alive = false; out.deferred = false; out.ro = f4_s(0.0f); out.rd = f4_s(0.0f); out.other = 0; out.overflow = false;
             const float4 nee0 = a.ps.nee0[slot];
@@ -539,6 +553,7 @@ __device__ __forceinline__ StageBOut stage_b(const DScene& s, const StageArgs& a
             if (mode != PT_NEE_DEAD)
             {
                 Ctx ctx = ctx_make();
+                if (SLOW) ctx.stack = stack;
                 { const uint4 r = a.ps.rng[slot]; ctx.rng.x = r.x; ctx.rng.y = r.y; ctx.rng.z = r.z; ctx.rng.w = r.w; }
                 v4 ro = ld4(a.ps.ro, slot), rd = ld4(a.ps.rd, slot);
                 v4 attenuation = ld4(a.ps.atten, slot);
@@ -662,6 +677,8 @@ __device__ __forceinline__ StageBOut stage_b(const DScene& s, const StageArgs& a
 template <bool SLOW>
 __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_shade_b(DScene s, StageArgs a)
 {
+    __shared__ unsigned long long sStack[SLOW ? PT_STACK_LDS * kShadeThreads : 1];
+    const LdsStack stack = kernel_stack(sStack, a);
     const int32_t count = SLOW ? a.counters[3] : a.counters[a.inSel];
     int32_t* countOut = &a.counters[a.inSel ^ 1];
     if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = 0;     /* next bounce's shade_a slow list starts empty */
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         {
             pos = SLOW ? a.slowB[idx] : idx;
             slot = a.queueIn[pos];
-            const StageBOut r = stage_b<SLOW>(s, a, slot, a.extHit[pos], a.neeD[pos], a.neeHit[pos], a.bounce);
+            const StageBOut r = stage_b<SLOW>(s, a, slot, a.extHit[pos], a.neeD[pos], a.neeHit[pos], a.bounce, stack);
             alive = r.alive; deferred = r.deferred; ro = r.ro; rd = r.rd;
             other += r.other; overflow |= r.overflow;
         }
@@ -731,9 +748,6 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
     bool have = false;
     int32_t slot = 0, b = 0;
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o;
-#ifdef PT_TAIL_TRIVIAL_STACK
-    TrivialStack st;
-#else
     /* the traversal stack of the two rays of a bounce: LDS (lane-interleaved) + spill area, as in k_trace -- a pop from
      * a private-memory stack is a memory round trip on the path's dependent chain */
     __shared__ unsigned long long sStack[PT_STACK_LDS * kTailThreads];
@@ -741,7 +755,6 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
     st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = kTailThreads;
     st.spillStride = (int64_t)gridDim.x * kTailThreads;
     st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * kTailThreads + threadIdx.x));
-#endif
     for (;;)
     {
         if ((int32_t)(threadIdx.x & 63) >= a.tailLanes) break;
@@ -753,11 +766,11 @@ __global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, St
         }
         const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
         ++ext;
-        const StageAOut ra = stage_a<true>(s, a, slot, eh, b);
+        const StageAOut ra = stage_a<true>(s, a, slot, eh, b, st);
         shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
         DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
         if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
-        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b);
+        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
         other += rb.other; overflow |= rb.overflow;
         have = rb.alive;
         o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
@@ -909,6 +922,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
     const int32_t tailBounce = tail_policy(g, n, bounceLimit);
     g.first = first; g.n = n; g.wavefrontBounces = 0; g.events.clear();
+    { int rcT = g.trace->ensure(); if (rcT) return rcT; }      /* the spill area behind the kernels' traversal stacks: gridBlocks * 256 lanes */
     int32_t init[64] = {}; init[0] = n;
     PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(g.stats, 0, 64, st));
@@ -928,7 +942,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         a.extO = w.extO[in] + first; a.extD = w.extD[in] + first; a.extHit = w.extHit + first; a.neeHit = w.neeHit + first;
         a.neeO = w.neeO + first; a.neeD = w.neeD + first;
         a.extOOut = w.extO[out] + first; a.extDOut = w.extD[out] + first; a.results = w.results; a.stats = g.stats;
-        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = nullptr;
+        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = g.trace->spill;
         if (b >= tailBounce)
         {
             /* the queue is short by now (or the caller forced it): one launch finishes every path.
@@ -937,8 +951,6 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
             const int64_t expect = (g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n;
             a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
             const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * kTailWavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
-            if ((rc = g.trace->ensure())) break;
-            a.spill = g.trace->spill;                   /* sized for gridBlocks * 256 lanes */
             const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
             k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
