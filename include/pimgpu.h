@@ -25,6 +25,7 @@
 #define PIMGPU_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -206,6 +207,11 @@ typedef struct PimTrace PimTrace;  /* device-side PtTrace (path_tracer.h:44-52) 
 int pimgpu_init(int device);
 int pimgpu_shutdown(void);
 const char* pimgpu_last_error(void);
+/* Host memory for the buffers a caller reads right after a call (PtTrace's images, Tex_Calloc in PtTrace_New,
+ * path_tracer.c:1126-1129): zeroed and page-locked, so that the device-to-host copies of pimgpu_trace_download run at
+ * the link's rate instead of through a pageable staging copy.  Any host pointer works everywhere; this one is faster. */
+void* pimgpu_host_alloc(size_t bytes);
+void pimgpu_host_free(void* p);
 /* the hipStream_t every call of the library runs on (for HIP events around a call: bench.py's roofline leg) */
 void* pimgpu_stream(void);
 /* measurement aid (no counterpart in the reference): with enable != 0 every closest-hit launch runs the COUNTING

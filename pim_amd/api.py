@@ -99,7 +99,7 @@ assert RAYHIT_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 36 and C.sizeof(
 
 # every symbol include/pimgpu.h declares (tests check that the built library exports all of them)
 EXPORTS = [
-    "pimgpu_init", "pimgpu_shutdown", "pimgpu_last_error",
+    "pimgpu_init", "pimgpu_shutdown", "pimgpu_last_error", "pimgpu_host_alloc", "pimgpu_host_free",
     "pimgpu_scene_create", "pimgpu_scene_destroy", "pimgpu_scene_rebuild_bvh", "pimgpu_scene_update_dists",
     "pimgpu_scene_info", "pimgpu_scene_download_lights",
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",

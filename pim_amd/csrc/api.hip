@@ -152,6 +152,19 @@ int pimgpu_init(int device)
     return PIMGPU_OK;
 }
 
+void* pimgpu_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error("host_alloc: %zu bytes of page-locked memory", bytes); return nullptr; }
+    memset(p, 0, bytes);
+    return p;
+}
+
+void pimgpu_host_free(void* p)
+{
+    if (p) hipHostFree(p);
+}
+
 int pimgpu_shutdown(void)
 {
     if (!g_lib.initialised) return PIMGPU_OK;

@@ -88,10 +88,11 @@ void PtTrace_New(PtTrace* trace, int2 imageSize)
     if (!texelCount) return;
     if (!ok(pimgpu_trace_create(imageSize.x, imageSize.y, &trace->gpu), "PtTrace_New")) return;
     trace->imageSize = imageSize;
-    trace->color = calloc(texelCount, sizeof(float3));
-    trace->albedo = calloc(texelCount, sizeof(float3));
-    trace->normal = calloc(texelCount, sizeof(float3));
-    trace->denoised = calloc(texelCount, sizeof(float3));
+    /* Tex_Calloc in the reference; page-locked here: Pt_Trace copies the three images back on every call */
+    trace->color = pimgpu_host_alloc(texelCount * sizeof(float3));
+    trace->albedo = pimgpu_host_alloc(texelCount * sizeof(float3));
+    trace->normal = pimgpu_host_alloc(texelCount * sizeof(float3));
+    trace->denoised = pimgpu_host_alloc(texelCount * sizeof(float3));
     trace->sampleWeight = 1.0f;
     trace->frameDt = 1.0f / 60.0f;
 }
@@ -100,7 +101,7 @@ void PtTrace_Del(PtTrace* trace)
 {
     if (!trace) return;
     pimgpu_trace_destroy(trace->gpu);
-    free(trace->color); free(trace->albedo); free(trace->normal); free(trace->denoised);
+    pimgpu_host_free(trace->color); pimgpu_host_free(trace->albedo); pimgpu_host_free(trace->normal); pimgpu_host_free(trace->denoised);
     memset(trace, 0, sizeof(*trace));
 }
 
