@@ -346,6 +346,22 @@ def flatten(drawables):
     return P, N, U, ids, mats
 
 
+def host_array(count, dtype=np.float32):
+    """a zeroed numpy array in page-locked host memory (pimgpu_host_alloc): host <-> device copies of it run at link rate.
+    The memory is freed when the array is collected."""
+    lib = load_library()
+    lib.pimgpu_host_alloc.restype = C.c_void_p
+    nbytes = int(count) * np.dtype(dtype).itemsize
+    p = lib.pimgpu_host_alloc(C.c_size_t(nbytes))
+    if not p:
+        raise PimGpuError("pimgpu_host_alloc failed: " + lib.pimgpu_last_error().decode())
+    buf = (C.c_char * nbytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(count))
+    import weakref
+    weakref.finalize(buf, lib.pimgpu_host_free, C.c_void_p(p))
+    return arr
+
+
 def _page_array(pages, lmSize):
     arr = (PimLightmapPage * max(1, len(pages)))()
     for i, p in enumerate(pages):

@@ -191,7 +191,9 @@ void Lightmap_New(Lightmap* lm, i32 size)
     if (size <= 0) return;
     lm->size = size;
     const size_t texelcount = (size_t)size * (size_t)size;
-    float* allocation = calloc(texelcount * 27, sizeof(float));      /* [5] float4 | float3 | float3 | float, lightmap.c:90-110 */
+    /* [5] float4 | float3 | float3 | float, lightmap.c:90-110; Tex_Calloc there, page-locked here: LmPack_Bake copies a
+     * page (113 MB at 1024^2) to the device and back on every call */
+    float* allocation = pimgpu_host_alloc(texelcount * 27 * sizeof(float));
     if (!allocation) { lm->size = 0; return; }
     for (i32 i = 0; i < 5; ++i) lm->probes[i] = (float4*)(allocation + texelcount * 4 * (size_t)i);
     lm->position = (float3*)(allocation + texelcount * 20);
@@ -201,7 +203,7 @@ void Lightmap_New(Lightmap* lm, i32 size)
 
 void Lightmap_Del(Lightmap* lm)
 {
-    if (lm) { free(lm->probes[0]); memset(lm, 0, sizeof(*lm)); }
+    if (lm) { pimgpu_host_free(lm->probes[0]); memset(lm, 0, sizeof(*lm)); }
 }
 
 void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, const i32* texIds, i32 lmCount)
