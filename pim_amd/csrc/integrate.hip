@@ -242,6 +242,7 @@ struct CameraArgs
     PimDofInfo dof;
     int32_t width, height;
     uint32_t sampleIndex, seed;
+    const float* focalDev;          /* non-null: dof.focalLength of this frame, left on the device by k_focus_update */
 };
 
 /* CalculateDof, pt.c:2418-2452 */
@@ -262,6 +263,16 @@ __device__ __forceinline__ void CalculateDof(Ctx& ctx, const PimDofInfo& dof, v4
     *rd = f4_normalize3(f4_sub(focusPos, aperturePos));
 }
 
+/* DofUpdate's smoothing (pt.c:2497-2501) on the device: the autofocus ray's hit stays in HBM, so the frame needs no host
+ * round trip between that ray and the camera rays; the host reads the new focal length back with the statistics */
+__global__ void k_focus_update(const DHit* __restrict__ hit, float focalLength, float tt, float* __restrict__ focalDev)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const DHit h = hit[0];
+    if (h.prim >= 0 && h.t > 0.0f) focalLength = f1_lerp(focalLength, h.t, tt);
+    *focalDev = focalLength;
+}
+
 /* TraceFn up to Pt_TraceRay, pt.c:2514-2545 */
 __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, float4* extD, int32_t* queue, CameraArgs c)
 {
@@ -276,7 +287,9 @@ __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, 
     const v2 rayUv = f2_add(baseUv, f2_mul(aa, f2_v(rcpX, rcpY)));
     v4 ro = c.eye;
     v4 rd = proj_dir(c.right, c.up, c.fwd, c.slope, f2_v(rayUv.x * 2.0f - 1.0f, rayUv.y * 2.0f - 1.0f));
-    CalculateDof(ctx, c.dof, c.right, c.up, c.fwd, &ro, &rd);
+    PimDofInfo dof = c.dof;
+    if (c.focalDev) dof.focalLength = *c.focalDev;
+    CalculateDof(ctx, dof, c.right, c.up, c.fwd, &ro, &rd);
     path_start(ps, extO, extD, queue, i, ctx, ro, rd);
 }
 
@@ -1136,6 +1149,8 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     const v4 rot = f4_v(cam->rotation[0], cam->rotation[1], cam->rotation[2], cam->rotation[3]);
     const v4 eye = f4_v(cam->position[0], cam->position[1], cam->position[2], cam->position[3]);
     uint64_t otherRays = 0;
+    float* focalDev = nullptr;
+    float focalHost = dof->focalLength;
     if (dof->autoFocus)                                                             /* DofUpdate, pt.c:2485-2503 */
     {
         const v4 fwd = quat_fwd(rot);
@@ -1143,15 +1158,10 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
         PT_HIP(hipMemcpyAsync(w.extO[0], &ro, sizeof(ro), hipMemcpyHostToDevice, st));
         PT_HIP(hipMemcpyAsync(w.extD[0], &rd, sizeof(rd), hipMemcpyHostToDevice, st));
         if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[0], w.extD[0], w.extHit, 1, nullptr, st))) return rc;
-        DHit h;
-        PT_HIP(hipMemcpyAsync(&h, w.extHit, sizeof(h), hipMemcpyDeviceToHost, st));
-        PT_HIP(hipStreamSynchronize(st));
+        focalDev = (float*)g_lib.trace.status + 20;                               /* spare words of the status block */
+        const float tt = 1.0f - pl_expf(-p->frameDt * dof->autoFocusSpeed);
+        k_focus_update<<<1, 64, 0, st>>>(w.extHit, dof->focalLength, tt, focalDev);
         otherRays = 1;
-        if (h.prim >= 0 && h.t > 0.0f)
-        {
-            const float tt = 1.0f - pl_expf(-p->frameDt * dof->autoFocusSpeed);
-            dof->focalLength = f1_lerp(dof->focalLength, h.t, tt);
-        }
     }
     CameraArgs c;
     c.eye = eye; c.right = quat_right(rot); c.up = quat_up(rot); c.fwd = quat_fwd(rot);
@@ -1160,13 +1170,15 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
         const float tn = pl_tanf(fovy * 0.5f);                                      /* proj_slope, frustum.h:26-30 */
         c.slope = f2_v(aspect * tn, tn);
     }
-    c.dof = *dof; c.width = t->width; c.height = t->height; c.sampleIndex = p->sampleIndex; c.seed = p->seed;
+    c.dof = *dof; c.width = t->width; c.height = t->height; c.sampleIndex = p->sampleIndex; c.seed = p->seed; c.focalDev = focalDev;
     k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
     if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr, [&](hipStream_t s)
-        { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, t->width, t->height, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s); }))) return rc;
+        { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, t->width, t->height, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s);
+          if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s); }))) return rc;
     PT_HIP(hipEventSynchronize(e1));
+    dof->focalLength = focalHost;                                                  /* DofUpdate updates the caller's struct */
     float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
     stats.otherRays += otherRays;

@@ -11,7 +11,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
   timeout -s KILL 170 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$n -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --workload $wl > $out/pmc_$n.log 2>&1 || { echo "pass $c failed"; exit 1; }
 done
 cd $R
-python3 scripts/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) > $out/kernel_stats.txt
+python3 scripts/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) 8 2 > $out/kernel_stats.txt
 python3 scripts/pmc_summary.py $out/pmc_* > $out/pmc_summary.txt
 grep -h '"metric"' $out/kt.log | tail -1 > $out/bench_line.json
 echo done $wl
