@@ -891,6 +891,12 @@ static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
     return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;
 }
 
+hipEvent_t PathGroup::take_event()
+{
+    if (eventsUsed == eventPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; eventPool.push_back(e); }
+    return eventPool[eventsUsed++];
+}
+
 int Library::ensure_group(int gi)
 {
     PathGroup& g = groups[gi];
@@ -912,12 +918,14 @@ int Library::ensure_group(int gi)
 
 void Library::release_groups()
 {
+    if (frameBegin) { hipEventDestroy(frameBegin); hipEventDestroy(frameEnd); frameBegin = frameEnd = nullptr; }
     for (int gi = 0; gi < kMaxGroups; ++gi)
     {
         PathGroup& g = groups[gi];
         if (!g.stream) continue;
         if (g.done) hipEventDestroy(g.done);
         if (g.stagger) hipEventDestroy(g.stagger);
+        for (hipEvent_t e : g.eventPool) hipEventDestroy(e);
         if (gi > 0) { hipStreamSynchronize(g.stream); hipStreamDestroy(g.stream); hipFree(g.counters); hipFree(g.stats); g.ownTrace.release(); }
         g = PathGroup();
     }
@@ -934,7 +942,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     hipStream_t st = g.stream;
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
     const int32_t tailBounce = tail_policy(g, n, bounceLimit);
-    g.first = first; g.n = n; g.wavefrontBounces = 0; g.events.clear();
+    g.first = first; g.n = n; g.wavefrontBounces = 0; g.events.clear(); g.eventsUsed = 0;
     { int rcT = g.trace->ensure(); if (rcT) return rcT; }      /* the spill area behind the kernels' traversal stacks: gridBlocks * 256 lanes */
     int32_t init[64] = {}; init[0] = n;
     PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -971,13 +979,13 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         }
         ++g.wavefrontBounces;
         t0 = t1 = nullptr;
-        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); g.events.push_back({ t0, t1 }); }
+        if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ t0, t1 }); else t0 = t1 = nullptr; }
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st, t0, t1))) break;
         k_shade_a<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_a<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
         half_done();
         t0 = t1 = nullptr;
-        if (timeTrace) { hipEventCreate(&t0); hipEventCreate(&t1); g.events.push_back({ t0, t1 }); }
+        if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ t0, t1 }); else t0 = t1 = nullptr; }
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st, t0, t1))) break;
         k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
         k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
@@ -998,7 +1006,7 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     PT_HIP(hipMemcpyAsync(counts, g.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
     float traceMs = 0.0f;
-    for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; }
     g.events.clear();
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow"); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
@@ -1141,8 +1149,8 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     const int32_t n = t->width * t->height;
     WorkBuffers& w = g_lib.work;
     if ((rc = w.ensure_paths(n))) return rc;
-    hipEvent_t e0, e1;
-    PT_HIP(hipEventCreate(&e0)); PT_HIP(hipEventCreate(&e1));
+    if (!g_lib.frameBegin) { PT_HIP(hipEventCreate(&g_lib.frameBegin)); PT_HIP(hipEventCreate(&g_lib.frameEnd)); }
+    hipEvent_t e0 = g_lib.frameBegin, e1 = g_lib.frameEnd;
     PT_HIP(hipEventRecord(e0, st));
     if (p->updateDists) { if ((rc = update_dists(scene->d, st))) return rc; }      /* PtScene_Update, pt.c:1034 */
 
@@ -1180,7 +1188,6 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     PT_HIP(hipEventSynchronize(e1));
     dof->focalLength = focalHost;                                                  /* DofUpdate updates the caller's struct */
     float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
     stats.otherRays += otherRays;
     stats.traceMs = traceMs; stats.totalMs = totalMs;
     t->stats = stats;

@@ -90,6 +90,9 @@ struct PathGroup
     /* the call in flight */
     int32_t first = 0, n = 0, wavefrontBounces = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<hipEvent_t> eventPool; size_t eventsUsed = 0;   /* timing events are made once and reused: creating and
+                                                                    destroying 14 per frame was host time with the GPU idle */
+    hipEvent_t take_event();
 };
 static constexpr int kMaxGroups = 8;
 
@@ -101,6 +104,7 @@ struct Library
     hipStream_t stream = nullptr;
     TraceResources trace;
     WorkBuffers work;
+    hipEvent_t frameBegin = nullptr, frameEnd = nullptr;     /* pimgpu_trace_image's totalMs */
     PathGroup groups[kMaxGroups];
     int ensure_group(int g);
     void release_groups();
