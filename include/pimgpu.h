@@ -365,6 +365,32 @@ int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCoun
     uint32_t passIndex, uint32_t seed, int32_t maxBounces,
     int64_t texelBegin, int64_t texelEnd);
 
+/* chartnode_t (lightmap.c:48-55), field for field at the same offsets: 64 bytes (the reference's float4 is 16-aligned) */
+typedef struct PimChartNode
+{
+    float   plane[4];           /* triToPlane: unit normal, distance */
+    float   triCoord[6];        /* the triangle on its own plane's tangent frame, in texels: a.xy, b.xy, c.xy */
+    float   area;               /* TriArea3D, world units */
+    int32_t drawableIndex;
+    int32_t vertIndex;
+    int32_t _pad[3];
+} PimChartNode;
+
+/* The data-parallel steps of LmPack_Pack (lightmap.c:1047-1102) around its sequential chart grouping and atlas search,
+ * which stay on the host:
+ *  chartnodes  = chartnodes_create (:723-767): one node per triangle of every mapped drawable (not MatFlag_Sky | MatFlag_Lava,
+ *                mesh present), world space through the entity's matrix.  nodes == NULL: only counts.
+ *  chart_layout = the first half of ChartMaskFn (:527-552): chart c owns nodes [chartFirst[c], chartFirst[c+1]); its
+ *                triangles move to the origin with a 2-texel margin (nodes updated in place), areas[c] = bounds area,
+ *                maskSizes[2c..] = mask width, height.
+ *  chart_masks = mask_tri over every node (:244-259, :553-557): texel = 0xff where sdTriangle2D <= kMaskPadding (1 texel)
+ *                of any of the chart's triangles, else 0; chart c's mask is maskSizes[2c] x maskSizes[2c+1] bytes at
+ *                masks + maskOffsets[c]. */
+int pimgpu_lightmap_chartnodes(const PimDrawables* drawables, float texelsPerUnit, PimChartNode* nodes, int32_t capacity, int32_t* nodeCount);
+int pimgpu_lightmap_chart_layout(PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, float* areas, int32_t* maskSizes);
+int pimgpu_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, const int32_t* maskSizes,
+    const int64_t* maskOffsets, uint8_t* masks);
+
 /* EmbedAttributes / EmbedTaskFn (lightmap.c:941-1045), the last step of LmPack_Pack (:1092) and the producer of
  * LmPack_Bake's inputs: every texel of every page takes the mapped triangle (texIndices[iVert].w == the page's texture
  * id; drawables with MatFlag_Sky | MatFlag_Lava and NULL meshes skipped) whose signed 2D distance (sdTriangle2D on

@@ -101,6 +101,11 @@ HOOK(lm_embed_fragment)
     fn = o4_normalize3(fn);
     PF(out, 0, sdTriangle2D(A, B, C, px)); PF(out, 1, sdEdge2D(A, B, C)); P3(out, 2, fp); P3(out, 5, fn);
 }
+HOOK(lm_chartnode)
+{
+    const OrcChartGeom g = ChartNodeGeom(F3(in, 0, 1.0f), F3(in, 3, 1.0f), F3(in, 6, 1.0f), F(in, 9));
+    P4(out, 0, g.plane); PF(out, 4, g.a.x); PF(out, 5, g.a.y); PF(out, 6, g.b.x); PF(out, 7, g.b.y); PF(out, 8, g.c.x); PF(out, 9, g.c.y); PF(out, 10, g.area);
+}
 HOOK(f2_tent) { v2 r = f2_tent(o2(F(in, 0), F(in, 1))); PF(out, 0, r.x); PF(out, 1, r.y); }
 HOOK(Cubemap_CalcDir) { v4 d = Cubemap_CalcDir((int32_t)in[0], (int)in[1], (int32_t)in[2], (int32_t)in[3], o2(F(in, 4), F(in, 5))); PF(out, 0, d.x); PF(out, 1, d.y); PF(out, 2, d.z); }
 HOOK(AmbCube_Fit)

@@ -752,6 +752,29 @@ ORC_INL void LmEmbedFragment(v2 A, v2 B, v2 C, v2 px, const v4* pos, const v4* n
     *fragNor = o4_normalize3(o4_blend(nor[0], nor[1], nor[2], wuv));
 }
 
+/* ---- lightmap chart nodes: math/sdf.h:251-257, rendering/lightmap.c:284-320 ---- */
+ORC_INL v4 triToPlane(v4 A, v4 B, v4 C)                                                           /* sdf.h:251-257 */
+{
+    v4 pl = o4_normalize3(o4_cross3(o4_sub(B, A), o4_sub(C, A)));
+    pl.w = o4_dot3(pl, A);
+    return pl;
+}
+typedef struct { v4 plane; v2 a, b, c; float area; } OrcChartGeom;
+/* chartnode_new (lightmap.c:302-320): plane, the triangle projected on its own plane's tangent frame (ProjTri :291-300)
+ * in texels, area */
+ORC_INL OrcChartGeom ChartNodeGeom(v4 A, v4 B, v4 C, float texelsPerUnit)
+{
+    OrcChartGeom g;
+    g.plane = triToPlane(A, B, C);
+    const m33 TBN = NormalToTBN(triToPlane(A, B, C));
+    g.a = o2_muls(o2(o4_dot3(TBN.c0, A), o4_dot3(TBN.c1, A)), texelsPerUnit);
+    g.b = o2_muls(o2(o4_dot3(TBN.c0, B), o4_dot3(TBN.c1, B)), texelsPerUnit);
+    g.c = o2_muls(o2(o4_dot3(TBN.c0, C), o4_dot3(TBN.c1, C)), texelsPerUnit);
+    g.area = TriArea3D(A, B, C);
+    return g;
+}
+#define ORC_LM_MASK_PADDING 1.0f                                                                  /* lightmap.c:39 */
+
 /* ---- participating media helpers: math/atmosphere.h:36-43, math/noise.h:16-83 ---- */
 ORC_INL float MiePhase(float cosTheta, float g)
 {

@@ -1959,3 +1959,87 @@ void orc_lightmap_embed(const PimDrawables* drawables, const int32_t* pageTexIds
     EmbedTask t = { drawables, pageTexIds, pages, lmSize };
     orc_parallel_for(embed_fn, &t, (int64_t)lmCount * lmSize * lmSize, threads);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* LmPack_Pack's data-parallel steps, rendering/lightmap.c                                     */
+
+/* chartnodes_create, :723-767 (nodes == NULL: counts only) */
+int32_t orc_lightmap_chartnodes(const PimDrawables* d, float texelsPerUnit, PimChartNode* nodes)
+{
+    int32_t nodeCount = 0;
+    for (int32_t di = 0; di < d->count; ++di)
+    {
+        if (d->materials[di].flags & (PIM_MATFLAG_SKY | PIM_MATFLAG_LAVA)) continue;
+        if (d->meshes[di] < 0) continue;
+        const PimMesh* mesh = &d->meshTable[d->meshes[di]];
+        const float* c = d->matrices + (size_t)di * 16;
+        m44 M;
+        M.c0 = o4(c[0], c[1], c[2], c[3]); M.c1 = o4(c[4], c[5], c[6], c[7]);
+        M.c2 = o4(c[8], c[9], c[10], c[11]); M.c3 = o4(c[12], c[13], c[14], c[15]);
+        int32_t nodeBack = nodeCount;
+        nodeCount += mesh->length / 3;
+        if (!nodes) continue;
+        for (int32_t v = 0; (v + 3) <= mesh->length; v += 3)
+        {
+            const v4 A = m44_mul_pt(M, ld4(mesh->positions, v)), B = m44_mul_pt(M, ld4(mesh->positions, v + 1)), C = m44_mul_pt(M, ld4(mesh->positions, v + 2));
+            const OrcChartGeom g = ChartNodeGeom(A, B, C, texelsPerUnit);
+            PimChartNode* n = &nodes[nodeBack++];
+            n->plane[0] = g.plane.x; n->plane[1] = g.plane.y; n->plane[2] = g.plane.z; n->plane[3] = g.plane.w;
+            n->triCoord[0] = g.a.x; n->triCoord[1] = g.a.y; n->triCoord[2] = g.b.x; n->triCoord[3] = g.b.y; n->triCoord[4] = g.c.x; n->triCoord[5] = g.c.y;
+            n->area = g.area; n->drawableIndex = di; n->vertIndex = v; n->_pad[0] = n->_pad[1] = n->_pad[2] = 0;
+        }
+    }
+    return nodeCount;
+}
+
+static void chart_minmax(const PimChartNode* nodes, int32_t first, int32_t last, v2* loOut, v2* hiOut)   /* :359-376 */
+{
+    const float bigNum = (float)(1 << 23);
+    v2 lo = o2(bigNum, bigNum), hi = o2(-bigNum, -bigNum);
+    for (int32_t i = first; i < last; ++i)
+        for (int k = 0; k < 3; ++k)
+        {
+            const v2 p = o2(nodes[i].triCoord[2 * k], nodes[i].triCoord[2 * k + 1]);
+            lo = o2_min(lo, p); hi = o2(o_max(hi.x, p.x), o_max(hi.y, p.y));
+        }
+    *loOut = lo; *hiOut = hi;
+}
+
+/* ChartMaskFn up to mask_new, :532-552 */
+void orc_lightmap_chart_layout(PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, float* areas, int32_t* maskSizes)
+{
+    for (int32_t c = 0; c < chartCount; ++c)
+    {
+        const int32_t first = chartFirst[c], last = chartFirst[c + 1];
+        v2 lo, hi;
+        chart_minmax(nodes, first, last, &lo, &hi);
+        lo = o2(lo.x - 2.0f, lo.y - 2.0f);
+        for (int32_t i = first; i < last; ++i)
+            for (int k = 0; k < 3; ++k) { nodes[i].triCoord[2 * k] -= lo.x; nodes[i].triCoord[2 * k + 1] -= lo.y; }
+        chart_minmax(nodes, first, last, &lo, &hi);
+        const v2 size = o2_sub(hi, lo);
+        areas[c] = size.x * size.y;
+        hi = o2(hi.x + 2.0f, hi.y + 2.0f);
+        maskSizes[2 * c] = (int32_t)hi.x; maskSizes[2 * c + 1] = (int32_t)hi.y;
+    }
+}
+
+/* mask_tri over every node of every chart, :244-259 and :553-557 */
+void orc_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, const int32_t* maskSizes,
+    const int64_t* maskOffsets, uint8_t* masks)
+{
+    for (int32_t c = 0; c < chartCount; ++c)
+    {
+        const int32_t sx = maskSizes[2 * c], sy = maskSizes[2 * c + 1];
+        uint8_t* mask = masks + maskOffsets[c];
+        memset(mask, 0, (size_t)sx * (size_t)sy);                          /* mask_new: Perm_Calloc */
+        for (int32_t i = chartFirst[c]; i < chartFirst[c + 1]; ++i)
+        {
+            const float* t = nodes[i].triCoord;
+            const v2 a = o2(t[0], t[1]), b = o2(t[2], t[3]), cc = o2(t[4], t[5]);
+            for (int32_t y = 0; y < sy; ++y)
+                for (int32_t x = 0; x < sx; ++x)
+                    if (sdTriangle2D(a, b, cc, o2(x + 0.5f, y + 0.5f)) <= ORC_LM_MASK_PADDING) mask[x + (size_t)y * sx] = 0xff;
+        }
+    }
+}

@@ -409,6 +409,27 @@ int main(int argc, char** argv)
     }
     end("lm_embed_fragment", N, 27, 8);
 
+    /* ---- lightmap chart node: chartnode_new (rendering/lightmap.c:302-320, static there) from the reference's own header
+     * functions in its order: triToPlane, ProjTri = NormalToTBN + two dot products per vertex, scale, TriArea3D ---- */
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        float4 A = f4_v(rnds(-60, 60), rnds(-60, 60), rnds(-60, 60), 1.0f);
+        float4 B = f4_v(A.x + rnds(-3, 3), A.y + rnds(-3, 3), A.z + rnds(-3, 3), 1.0f);
+        float4 C = f4_v(A.x + rnds(-3, 3), A.y + rnds(-3, 3), A.z + rnds(-3, 3), 1.0f);
+        if ((i & 7) == 3) { B.z = A.z; C.z = A.z; }                 /* axis-aligned faces: normals (0, 0, +-1) */
+        if ((i & 7) == 5) { B.x = A.x; C.x = A.x; }
+        const float tpu = (i & 1) ? 16.0f : 2.5f;
+        Plane3D plane = triToPlane(A, B, C);
+        float3x3 TBN = NormalToTBN(plane.value);
+        float2 a = f2_mulvs(f2_v(f4_dot3(TBN.c0, A), f4_dot3(TBN.c1, A)), tpu);
+        float2 b = f2_mulvs(f2_v(f4_dot3(TBN.c0, B), f4_dot3(TBN.c1, B)), tpu);
+        float2 c = f2_mulvs(f2_v(f4_dot3(TBN.c0, C), f4_dot3(TBN.c1, C)), tpu);
+        PUT3(A); PUT3(B); PUT3(C); putf(tpu);
+        PUT4(plane.value); putf(a.x); putf(a.y); putf(b.x); putf(b.y); putf(c.x); putf(c.y); putf(TriArea3D(A, B, C));
+    }
+    end("lm_chartnode", N, 10, 11);
+
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);
     fclose(s_out);

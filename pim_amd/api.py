@@ -87,6 +87,15 @@ class PimDrawables(C.Structure):
                 ("materials", C.c_void_p), ("meshTable", C.c_void_p)]
 
 
+class PimChartNode(C.Structure):
+    _fields_ = [("plane", C.c_float * 4), ("triCoord", C.c_float * 6), ("area", C.c_float), ("drawableIndex", C.c_int32),
+                ("vertIndex", C.c_int32), ("_pad", C.c_int32 * 3)]
+
+
+CHARTNODE_DTYPE = np.dtype([("plane", np.float32, 4), ("triCoord", np.float32, 6), ("area", np.float32),
+                            ("drawableIndex", np.int32), ("vertIndex", np.int32), ("_pad", np.int32, 3)])
+
+
 class PimLightmapPage(C.Structure):
     _fields_ = [("block", C.c_void_p)]
 
@@ -106,7 +115,7 @@ EXPORTS = [
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
-    "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed",
+    "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
 ]
 
@@ -378,6 +387,31 @@ def lightmap_embed(drawables, pages, lmSize, page_tex_ids=None):
     check(load_library().pimgpu_lightmap_embed(C.byref(drawables.desc), None if ids is None else _ptr(ids),
           _page_array(pages, lmSize), C.c_int32(len(pages)), C.c_int32(lmSize)), "pimgpu_lightmap_embed")
     return pages
+
+
+def lightmap_chartnodes(drawables, texelsPerUnit):
+    """chartnodes_create (rendering/lightmap.c:723-767) -> structured array of CHARTNODE_DTYPE, one per mapped triangle"""
+    lib = load_library()
+    n = C.c_int32()
+    check(lib.pimgpu_lightmap_chartnodes(C.byref(drawables.desc), C.c_float(texelsPerUnit), None, C.c_int32(0), C.byref(n)), "pimgpu_lightmap_chartnodes")
+    nodes = np.zeros(n.value, CHARTNODE_DTYPE)
+    check(lib.pimgpu_lightmap_chartnodes(C.byref(drawables.desc), C.c_float(texelsPerUnit), _ptr(nodes), C.c_int32(n.value), C.byref(n)), "pimgpu_lightmap_chartnodes")
+    return nodes
+
+
+def lightmap_chart_masks(nodes, chartFirst):
+    """ChartMaskFn (rendering/lightmap.c:527-561): nodes (CHARTNODE_DTYPE, charts contiguous) are moved to their chart's
+    origin in place; returns (areas, maskSizes (charts, 2), maskOffsets, masks uint8)"""
+    lib = load_library()
+    first = np.ascontiguousarray(chartFirst, np.int32)
+    nc = first.shape[0] - 1
+    areas, sizes = np.zeros(nc, np.float32), np.zeros((nc, 2), np.int32)
+    check(lib.pimgpu_lightmap_chart_layout(_ptr(nodes), _ptr(first), C.c_int32(nc), _ptr(areas), _ptr(sizes)), "pimgpu_lightmap_chart_layout")
+    lens = sizes[:, 0].astype(np.int64) * sizes[:, 1]
+    offsets = np.zeros(nc, np.int64); offsets[1:] = np.cumsum(lens)[:-1]
+    masks = np.full(int(lens.sum()), 7, np.uint8)
+    check(lib.pimgpu_lightmap_chart_masks(_ptr(nodes), _ptr(first), C.c_int32(nc), _ptr(sizes), _ptr(offsets), _ptr(masks)), "pimgpu_lightmap_chart_masks")
+    return areas, sizes, offsets, masks
 
 
 def brdf_lut_bake(texels, prevSamples, numSamples, seed=0):

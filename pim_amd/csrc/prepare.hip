@@ -214,6 +214,127 @@ __global__ __launch_bounds__(256) void k_embed_resolve(EmbedArgs a)
     a.normal[i * 3 + 0] = lmNor.x; a.normal[i * 3 + 1] = lmNor.y; a.normal[i * 3 + 2] = lmNor.z;
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* LmPack_Pack's data-parallel steps: chartnodes_create, ChartMaskFn (rendering/lightmap.c)        */
+
+struct DChartEntity
+{
+    m44 M;                       /* Entities.matrices[d] */
+    const v4* positions;
+    int32_t drawable;            /* index in the draw table (chartnode_t.drawableIndex) */
+    int32_t nodeBack;            /* first node of the entity, lightmap.c:751 */
+    int32_t triCount;
+};
+
+/* chartnodes_create, lightmap.c:723-767: one lane per triangle */
+__global__ __launch_bounds__(256) void k_chartnodes(const DChartEntity* __restrict__ ents, int32_t entCount, int32_t nodeCount,
+    float texelsPerUnit, PimChartNode* __restrict__ nodes)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodeCount) return;
+    int32_t lo = 0, hi = entCount - 1;
+    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (ents[mid].nodeBack <= i) lo = mid; else hi = mid - 1; }
+    const DChartEntity e = ents[lo];
+    const int32_t v = (i - e.nodeBack) * 3;
+    const v4 A = m44_mul_pt(e.M, e.positions[v]), B = m44_mul_pt(e.M, e.positions[v + 1]), C = m44_mul_pt(e.M, e.positions[v + 2]);
+    const ChartGeom g = ChartNodeGeom(A, B, C, texelsPerUnit);
+    PimChartNode n;
+    n.plane[0] = g.plane.x; n.plane[1] = g.plane.y; n.plane[2] = g.plane.z; n.plane[3] = g.plane.w;
+    n.triCoord[0] = g.a.x; n.triCoord[1] = g.a.y; n.triCoord[2] = g.b.x; n.triCoord[3] = g.b.y; n.triCoord[4] = g.c.x; n.triCoord[5] = g.c.y;
+    n.area = g.area; n.drawableIndex = e.drawable; n.vertIndex = v; n._pad[0] = n._pad[1] = n._pad[2] = 0;
+    nodes[i] = n;
+}
+
+__device__ __forceinline__ float wave_min_f(float v) { for (int o = 32; o > 0; o >>= 1) v = f1_min(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = f1_max(v, __shfl_xor(v, o, 64)); return v; }
+
+/* bounds of a chart's triangles (chart_minmax, lightmap.c:359-376): min and max do not depend on the order */
+__device__ __forceinline__ void chart_bounds(const PimChartNode* __restrict__ nodes, int32_t first, int32_t last, v2* lo, v2* hi)
+{
+    const float bigNum = (float)(1 << 23);
+    float lx = bigNum, ly = bigNum, hx = -bigNum, hy = -bigNum;
+    for (int32_t i = first + (int32_t)(threadIdx.x & 63); i < last; i += 64)
+        for (int k = 0; k < 3; ++k)
+        {
+            const float x = nodes[i].triCoord[2 * k], y = nodes[i].triCoord[2 * k + 1];
+            lx = f1_min(lx, x); ly = f1_min(ly, y); hx = f1_max(hx, x); hy = f1_max(hy, y);
+        }
+    *lo = f2_v(wave_min_f(lx), wave_min_f(ly)); *hi = f2_v(wave_max_f(hx), wave_max_f(hy));
+}
+
+/* ChartMaskFn up to mask_new, lightmap.c:532-552: one wave per chart */
+__global__ __launch_bounds__(64) void k_chart_layout(PimChartNode* __restrict__ nodes, const int32_t* __restrict__ chartFirst, int32_t chartCount,
+    float* __restrict__ areas, int32_t* __restrict__ maskSizes)
+{
+    const int32_t c = blockIdx.x;
+    if (c >= chartCount) return;
+    const int32_t first = chartFirst[c], last = chartFirst[c + 1];
+    v2 lo, hi;
+    chart_bounds(nodes, first, last, &lo, &hi);
+    lo = f2_v(lo.x - 2.0f, lo.y - 2.0f);
+    /* move to the origin and take the new bounds from the moved coordinates as they are written */
+    const float bigNum = (float)(1 << 23);
+    float lx = bigNum, ly = bigNum, hx = -bigNum, hy = -bigNum;
+    for (int32_t i = first + (int32_t)threadIdx.x; i < last; i += 64)
+        for (int k = 0; k < 3; ++k)
+        {
+            const float x = nodes[i].triCoord[2 * k] - lo.x, y = nodes[i].triCoord[2 * k + 1] - lo.y;
+            nodes[i].triCoord[2 * k] = x; nodes[i].triCoord[2 * k + 1] = y;
+            lx = f1_min(lx, x); ly = f1_min(ly, y); hx = f1_max(hx, x); hy = f1_max(hy, y);
+        }
+    lo = f2_v(wave_min_f(lx), wave_min_f(ly)); hi = f2_v(wave_max_f(hx), wave_max_f(hy));
+    if (threadIdx.x == 0)
+    {
+        const v2 size = f2_sub(hi, lo);
+        areas[c] = size.x * size.y;
+        maskSizes[2 * c] = (int32_t)(hi.x + 2.0f); maskSizes[2 * c + 1] = (int32_t)(hi.y + 2.0f);
+    }
+}
+
+struct ChartMaskArgs
+{
+    const PimChartNode* nodes; const int32_t* nodeChart;   /* chart of every node */
+    int32_t nodeCount;
+    const int32_t* maskSizes; const int64_t* maskOffsets; uint8_t* masks;
+};
+
+/* mask_tri (lightmap.c:244-259) for every node: one wave per node over the texels its padded bounds cover (the whole mask
+ * for slivers, where the bounds argument of k_embed_raster does not hold); every writer stores the same 0xff */
+__global__ __launch_bounds__(256) void k_chart_masks(ChartMaskArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int32_t wavesTotal = (int32_t)gridDim.x * 4;
+    for (int32_t i = (int32_t)blockIdx.x * 4 + (int32_t)(threadIdx.x >> 6); i < a.nodeCount; i += wavesTotal)
+    {
+        const int32_t c = a.nodeChart[i];
+        const int32_t sx = a.maskSizes[2 * c], sy = a.maskSizes[2 * c + 1];
+        if (sx <= 0 || sy <= 0) continue;
+        uint8_t* mask = a.masks + a.maskOffsets[c];
+        const float* t = a.nodes[i].triCoord;
+        const v2 A = f2_v(t[0], t[1]), B = f2_v(t[2], t[3]), C = f2_v(t[4], t[5]);
+        const v2 ba = f2_sub(B, A), cb = f2_sub(C, B), ac = f2_sub(A, C);
+        const float area2 = f1_abs(ba.x * ac.y - ba.y * ac.x);
+        const float lmax2 = f1_max(f2_dot(ba, ba), f1_max(f2_dot(cb, cb), f2_dot(ac, ac)));
+        const float lox = f1_min(A.x, f1_min(B.x, C.x)), hix = f1_max(A.x, f1_max(B.x, C.x));
+        const float loy = f1_min(A.y, f1_min(B.y, C.y)), hiy = f1_max(A.y, f1_max(B.y, C.y));
+        const bool bounded = (area2 > 1.0e-5f * lmax2) && lox > -1.0e5f && loy > -1.0e5f && hix < 1.0e5f && hiy < 1.0e5f;
+        int32_t x0 = 0, x1 = sx - 1, y0 = 0, y1 = sy - 1;
+        if (bounded)
+        {
+            x0 = (int32_t)f1_max(lox - 3.0f, 0.0f); y0 = (int32_t)f1_max(loy - 3.0f, 0.0f);
+            x1 = (int32_t)f1_min(hix + 3.0f, (float)(sx - 1)); y1 = (int32_t)f1_min(hiy + 3.0f, (float)(sy - 1));
+        }
+        const int32_t w = x1 - x0 + 1, h = y1 - y0 + 1;
+        if (w <= 0 || h <= 0) continue;
+        const int64_t cells = (int64_t)w * h;
+        for (int64_t k = lane; k < cells; k += 64)
+        {
+            const int32_t x = x0 + (int32_t)(k % w), y = y0 + (int32_t)(k / w);
+            if (sdTriangle2D(A, B, C, f2_v(x + 0.5f, y + 0.5f)) <= PT_LM_MASK_PADDING) mask[x + (int64_t)y * sx] = 0xff;
+        }
+    }
+}
+
 } /* namespace pt */
 
 using namespace pt;
@@ -418,6 +539,130 @@ int pimgpu_lightmap_embed(const PimDrawables* d, const int32_t* pageTexIds, PimL
         PT_HIP(hipMemcpyAsync(block + lmLen * 20, a.position + 3 * lmLen * i, sizeof(float) * 3 * (size_t)lmLen, hipMemcpyDeviceToHost, st));
         PT_HIP(hipMemcpyAsync(block + lmLen * 23, a.normal + 3 * lmLen * i, sizeof(float) * 3 * (size_t)lmLen, hipMemcpyDeviceToHost, st));
         PT_HIP(hipMemcpyAsync(block + lmLen * 26, a.sampleCounts + lmLen * i, sizeof(float) * (size_t)lmLen, hipMemcpyDeviceToHost, st));
+    }
+    PT_HIP(hipStreamSynchronize(st));
+    return PIMGPU_OK;
+}
+
+int pimgpu_lightmap_chartnodes(const PimDrawables* d, float texelsPerUnit, PimChartNode* nodes, int32_t capacity, int32_t* nodeCount)
+{
+    int rc = flatten_validate(d, "lightmap_chartnodes"); if (rc) return rc;
+    if (!nodeCount) { set_error("lightmap_chartnodes: NULL nodeCount"); return PIMGPU_E_INVALID; }
+    int64_t count = 0;
+    for (int32_t i = 0; i < d->count; ++i)
+        if (d->meshes[i] >= 0 && !(d->materials[i].flags & (PIM_MATFLAG_SKY | PIM_MATFLAG_LAVA))) count += d->meshTable[d->meshes[i]].length / 3;
+    if (count > 0x7fffffffll) { set_error("lightmap_chartnodes: %lld nodes", (long long)count); return PIMGPU_E_LIMIT; }
+    *nodeCount = (int32_t)count;
+    if (!nodes || count == 0) return PIMGPU_OK;                       /* the sizing pass */
+    if ((rc = check_ready())) return rc;
+    if (capacity < count) { set_error("lightmap_chartnodes: room for %d of %lld nodes", capacity, (long long)count); return PIMGPU_E_INVALID; }
+    hipStream_t st = g_lib.stream;
+    std::vector<DevBuf> meshBufs((size_t)d->meshCount);
+    std::vector<DChartEntity> ents;
+    int32_t nodeBack = 0;
+    for (int32_t i = 0; i < d->count; ++i)
+    {
+        const int32_t m = d->meshes[i];
+        if (m < 0 || (d->materials[i].flags & (PIM_MATFLAG_SKY | PIM_MATFLAG_LAVA))) continue;
+        const PimMesh& mesh = d->meshTable[m];
+        if (mesh.length < 3) continue;
+        if (!meshBufs[(size_t)m].p)
+        {
+            if ((rc = meshBufs[(size_t)m].alloc(sizeof(v4) * (size_t)mesh.length))) return rc;
+            PT_HIP(hipMemcpyAsync(meshBufs[(size_t)m].p, mesh.positions, sizeof(v4) * (size_t)mesh.length, hipMemcpyHostToDevice, st));
+        }
+        DChartEntity e;
+        const float* c = d->matrices + (size_t)i * 16;
+        e.M.c0 = f4_v(c[0], c[1], c[2], c[3]); e.M.c1 = f4_v(c[4], c[5], c[6], c[7]);
+        e.M.c2 = f4_v(c[8], c[9], c[10], c[11]); e.M.c3 = f4_v(c[12], c[13], c[14], c[15]);
+        e.positions = (const v4*)meshBufs[(size_t)m].p; e.drawable = i; e.nodeBack = nodeBack; e.triCount = mesh.length / 3;
+        nodeBack += e.triCount;
+        ents.push_back(e);
+    }
+    DevBuf entBuf, nodeBuf;
+    if ((rc = entBuf.alloc(sizeof(DChartEntity) * ents.size()))) return rc;
+    if ((rc = nodeBuf.alloc(sizeof(PimChartNode) * (size_t)count))) return rc;
+    PT_HIP(hipMemcpyAsync(entBuf.p, ents.data(), sizeof(DChartEntity) * ents.size(), hipMemcpyHostToDevice, st));
+    k_chartnodes<<<(unsigned)((count + 255) / 256), 256, 0, st>>>((const DChartEntity*)entBuf.p, (int32_t)ents.size(), (int32_t)count, texelsPerUnit, (PimChartNode*)nodeBuf.p);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemcpyAsync(nodes, nodeBuf.p, sizeof(PimChartNode) * (size_t)count, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    return PIMGPU_OK;
+}
+
+static int chart_args_check(const char* who, const void* nodes, const int32_t* chartFirst, int32_t chartCount)
+{
+    if (chartCount < 0 || (chartCount > 0 && (!nodes || !chartFirst))) { set_error("%s: bad chart arguments", who); return PIMGPU_E_INVALID; }
+    for (int32_t c = 0; c < chartCount; ++c)
+        if (chartFirst[c] < 0 || chartFirst[c + 1] <= chartFirst[c]) { set_error("%s: chart %d is empty or out of order", who, c); return PIMGPU_E_INVALID; }
+    return PIMGPU_OK;
+}
+
+int pimgpu_lightmap_chart_layout(PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, float* areas, int32_t* maskSizes)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if ((rc = chart_args_check("lightmap_chart_layout", nodes, chartFirst, chartCount))) return rc;
+    if (chartCount == 0) return PIMGPU_OK;
+    if (!areas || !maskSizes) { set_error("lightmap_chart_layout: NULL output"); return PIMGPU_E_INVALID; }
+    hipStream_t st = g_lib.stream;
+    const size_t nodeCount = (size_t)chartFirst[chartCount];
+    DevBuf nodeBuf, firstBuf, outBuf;
+    if ((rc = nodeBuf.alloc(sizeof(PimChartNode) * nodeCount))) return rc;
+    if ((rc = firstBuf.alloc(sizeof(int32_t) * ((size_t)chartCount + 1)))) return rc;
+    if ((rc = outBuf.alloc(12 * (size_t)chartCount))) return rc;
+    PT_HIP(hipMemcpyAsync(nodeBuf.p, nodes, sizeof(PimChartNode) * nodeCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(firstBuf.p, chartFirst, sizeof(int32_t) * ((size_t)chartCount + 1), hipMemcpyHostToDevice, st));
+    float* areasDev = (float*)outBuf.p; int32_t* sizesDev = (int32_t*)(areasDev + chartCount);
+    k_chart_layout<<<chartCount, 64, 0, st>>>((PimChartNode*)nodeBuf.p, (const int32_t*)firstBuf.p, chartCount, areasDev, sizesDev);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemcpyAsync(nodes, nodeBuf.p, sizeof(PimChartNode) * nodeCount, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(areas, areasDev, sizeof(float) * (size_t)chartCount, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipMemcpyAsync(maskSizes, sizesDev, 8 * (size_t)chartCount, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    return PIMGPU_OK;
+}
+
+int pimgpu_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, const int32_t* maskSizes,
+    const int64_t* maskOffsets, uint8_t* masks)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if ((rc = chart_args_check("lightmap_chart_masks", nodes, chartFirst, chartCount))) return rc;
+    if (chartCount == 0) return PIMGPU_OK;
+    if (!maskSizes || !maskOffsets || !masks) { set_error("lightmap_chart_masks: NULL argument"); return PIMGPU_E_INVALID; }
+    int64_t total = 0;
+    for (int32_t c = 0; c < chartCount; ++c)
+    {
+        const int64_t sx = maskSizes[2 * c], sy = maskSizes[2 * c + 1];
+        if (sx < 0 || sy < 0 || sx > 65536 || sy > 65536 || maskOffsets[c] < 0) { set_error("lightmap_chart_masks: chart %d has a bad mask size or offset", c); return PIMGPU_E_INVALID; }
+        total = std::max<int64_t>(total, maskOffsets[c] + sx * sy);
+    }
+    if (total == 0) return PIMGPU_OK;
+    hipStream_t st = g_lib.stream;
+    const size_t nodeCount = (size_t)chartFirst[chartCount];
+    std::vector<int32_t> nodeChart(nodeCount);
+    for (int32_t c = 0; c < chartCount; ++c) for (int32_t i = chartFirst[c]; i < chartFirst[c + 1]; ++i) nodeChart[(size_t)i] = c;
+    DevBuf nodeBuf, chartBuf, sizeBuf, offBuf, maskBuf;
+    if ((rc = nodeBuf.alloc(sizeof(PimChartNode) * nodeCount))) return rc;
+    if ((rc = chartBuf.alloc(sizeof(int32_t) * nodeCount))) return rc;
+    if ((rc = sizeBuf.alloc(8 * (size_t)chartCount))) return rc;
+    if ((rc = offBuf.alloc(8 * (size_t)chartCount))) return rc;
+    if ((rc = maskBuf.alloc((size_t)total))) return rc;
+    PT_HIP(hipMemcpyAsync(nodeBuf.p, nodes, sizeof(PimChartNode) * nodeCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(chartBuf.p, nodeChart.data(), sizeof(int32_t) * nodeCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(sizeBuf.p, maskSizes, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(offBuf.p, maskOffsets, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(maskBuf.p, 0, (size_t)total, st));
+    ChartMaskArgs a;
+    a.nodes = (const PimChartNode*)nodeBuf.p; a.nodeChart = (const int32_t*)chartBuf.p; a.nodeCount = (int32_t)nodeCount;
+    a.maskSizes = (const int32_t*)sizeBuf.p; a.maskOffsets = (const int64_t*)offBuf.p; a.masks = (uint8_t*)maskBuf.p;
+    const int blocks = (int)std::min<int64_t>(((int64_t)nodeCount + 3) / 4, (int64_t)g_lib.cuCount * 64);
+    k_chart_masks<<<blocks, 256, 0, st>>>(a);
+    PT_HIP(hipGetLastError());
+    /* charts' masks may be laid out with gaps: copy back chart by chart what the call owns */
+    for (int32_t c = 0; c < chartCount; ++c)
+    {
+        const size_t bytes = (size_t)maskSizes[2 * c] * (size_t)maskSizes[2 * c + 1];
+        if (bytes) PT_HIP(hipMemcpyAsync(masks + maskOffsets[c], (uint8_t*)maskBuf.p + maskOffsets[c], bytes, hipMemcpyDeviceToHost, st));
     }
     PT_HIP(hipStreamSynchronize(st));
     return PIMGPU_OK;

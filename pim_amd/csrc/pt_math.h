@@ -863,6 +863,29 @@ PT_FN void LmEmbedFragment(v2 A, v2 B, v2 C, v2 px, const v4* pos, const v4* nor
 
 /* ---- geometry helpers: math/area.h:28, math/sdf.h:158-189 ---- */
 PT_FN float TriArea3D(v4 A, v4 B, v4 C) { return 0.5f * f4_length3(f4_cross3(f4_sub(B, A), f4_sub(C, A))); }
+/* ---- lightmap chart nodes: math/sdf.h:251-257, rendering/lightmap.c:284-320 ---- */
+PT_FN v4 triToPlane(v4 A, v4 B, v4 C)                                                             /* sdf.h:251-257 */
+{
+    v4 pl = f4_normalize3(f4_cross3(f4_sub(B, A), f4_sub(C, A)));
+    pl.w = f4_dot3(pl, A);
+    return pl;
+}
+struct ChartGeom { v4 plane; v2 a, b, c; float area; };
+/* chartnode_new (lightmap.c:302-320): plane, the triangle projected on its own plane's tangent frame (ProjTri :291-300)
+ * in texels, area */
+PT_FN ChartGeom ChartNodeGeom(v4 A, v4 B, v4 C, float texelsPerUnit)
+{
+    ChartGeom g;
+    g.plane = triToPlane(A, B, C);
+    const m33 TBN = NormalToTBN(triToPlane(A, B, C));
+    g.a = f2_muls(f2_v(f4_dot3(TBN.c0, A), f4_dot3(TBN.c1, A)), texelsPerUnit);
+    g.b = f2_muls(f2_v(f4_dot3(TBN.c0, B), f4_dot3(TBN.c1, B)), texelsPerUnit);
+    g.c = f2_muls(f2_v(f4_dot3(TBN.c0, C), f4_dot3(TBN.c1, C)), texelsPerUnit);
+    g.area = TriArea3D(A, B, C);
+    return g;
+}
+#define PT_LM_MASK_PADDING 1.0f                                                                   /* lightmap.c:39 */
+
 PT_FN float sdTriangle3D(v4 a, v4 b, v4 c, v4 p)
 {
     v4 ba = f4_sub(b, a); v4 pa = f4_sub(p, a);

@@ -162,3 +162,36 @@ def world_mesh_with_charts(sc, lm_size, texels_per_meter, max_pages=2):
     m = api.PimMaterial(); m.flags = 0
     M = np.zeros((1, 4, 4), np.float32); M[0, 0, 0] = M[0, 1, 1] = M[0, 2, 2] = M[0, 3, 3] = 1.0
     return api.Drawables([(Pm, Nm, U, T)], np.zeros(1, np.int32), M, [m]), min(page + 1, max_pages)
+
+
+# ---------------------------------------------------------------------------------------------
+# LmPack_Pack's data-parallel steps (chartnodes_create, ChartMaskFn)
+
+def oracle_chartnodes(lib, dr, tpu):
+    lib.orc_lightmap_chartnodes.restype = C.c_int32
+    n = lib.orc_lightmap_chartnodes(C.byref(dr.desc), C.c_float(tpu), None)
+    nodes = np.zeros(n, api.CHARTNODE_DTYPE)
+    assert lib.orc_lightmap_chartnodes(C.byref(dr.desc), C.c_float(tpu), nodes.ctypes.data_as(C.c_void_p)) == n
+    return nodes
+
+
+def chart_partition(n_nodes, seed=3, sizes=(1, 2, 5, 40)):
+    """charts as contiguous runs of nodes (the reference groups by plane; any grouping exercises the same arithmetic)"""
+    rng = np.random.default_rng(seed)
+    first = [0]
+    while first[-1] < n_nodes:
+        first.append(min(n_nodes, first[-1] + int(rng.choice(sizes))))
+    return np.asarray(first, np.int32)
+
+
+def oracle_chart_masks(lib, nodes, first):
+    nc = first.shape[0] - 1
+    areas, sizes = np.zeros(nc, np.float32), np.zeros((nc, 2), np.int32)
+    lib.orc_lightmap_chart_layout.restype = None; lib.orc_lightmap_chart_masks.restype = None
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.orc_lightmap_chart_layout(p(nodes), p(first), C.c_int32(nc), p(areas), p(sizes))
+    lens = sizes[:, 0].astype(np.int64) * sizes[:, 1]
+    offsets = np.zeros(nc, np.int64); offsets[1:] = np.cumsum(lens)[:-1]
+    masks = np.full(int(lens.sum()), 7, np.uint8)
+    lib.orc_lightmap_chart_masks(p(nodes), p(first), C.c_int32(nc), p(sizes), p(offsets), p(masks))
+    return areas, sizes, offsets, masks

@@ -178,3 +178,45 @@ def test_lightmap_embed_feeds_the_bake():
     lit = sum(int((pu.page_parts(p, S)[0].reshape(5, S * S, 4)[:, :, :3].sum(axis=(0, 2)) > 0).sum()) for p in pg)
     assert lit > 100
     g.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# chartnodes_create, ChartMaskFn (rendering/lightmap.c:723-767, 527-561)
+
+@pytest.mark.parametrize("count,tpu,sizes", [(9, 3.0, (1, 2, 5, 40)), (40, 1.5, (1, 3, 17)), (3, 8.0, (1,))])
+def test_chartnodes_and_masks_bit_exact(count, tpu, sizes):
+    from tests import prepare_util as pu
+    gpu_init()
+    lib = load_oracle(True)
+    dr = pu.draw_table(count=count, seed=count)
+    want = pu.oracle_chartnodes(lib, dr, tpu)
+    got = api.lightmap_chartnodes(dr, tpu)
+    assert got.shape == want.shape and got.shape[0] > 0
+    assert_bits_equal(got.view(np.uint32).reshape(got.shape[0], -1), want.view(np.uint32).reshape(want.shape[0], -1), "chart nodes")
+    first = pu.chart_partition(got.shape[0], seed=count, sizes=sizes)
+    nodes_o = want.copy()
+    ao, so, oo, mo = pu.oracle_chart_masks(lib, nodes_o, first)
+    ag, sg, og, mg = api.lightmap_chart_masks(got, first)
+    assert_bits_equal(got.view(np.uint32).reshape(got.shape[0], -1), nodes_o.view(np.uint32).reshape(got.shape[0], -1), "moved nodes")
+    assert_bits_equal(ag, ao, "chart areas")
+    assert (sg == so).all() and (og == oo).all()
+    assert mg.shape == mo.shape and (mg == mo).all() and (mg == 255).any()
+
+
+def test_chart_masks_sliver_floods_and_bad_arguments():
+    """a zero-area triangle: sdTriangle2D calls every texel inside, so mask_tri sets the whole mask (as the reference)"""
+    from tests import prepare_util as pu
+    gpu_init()
+    lib = load_oracle(True)
+    nodes = np.zeros(3, api.CHARTNODE_DTYPE)
+    nodes["triCoord"][0] = [0, 0, 9, 3, 2, 8]
+    nodes["triCoord"][1] = [20, 20, 26, 20, 32, 20]                              # collinear
+    nodes["triCoord"][2] = [5, 5, 5, 5, 40, 30]                                  # zero-length edge
+    first = np.asarray([0, 1, 2, 3], np.int32)
+    want = pu.oracle_chart_masks(lib, nodes.copy(), first)
+    got = api.lightmap_chart_masks(nodes, first)
+    assert (got[1] == want[1]).all() and (got[3] == want[3]).all()
+    a1 = got[3][got[2][1]:got[2][2]]
+    assert (a1 == 255).all()                                                      # the collinear triangle's mask is flooded
+    with pytest.raises(api.PimGpuError):
+        api.lightmap_chart_masks(nodes, np.asarray([0, 2, 2, 3], np.int32))      # an empty chart

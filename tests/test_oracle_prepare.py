@@ -138,3 +138,66 @@ def test_embed_matches_the_pairwise_golden_function():
     plain = pu.oracle_embed(lib, pu.embed_table(S, ids, tris_per_mesh=(20, 30), chart_texels=(1.5, 6.0), hard_cases=False),
                             pu.new_pages(2, S), S, page_tex_ids=ids)
     assert all(0.05 < pu.page_parts(p, S)[3].mean() < 0.95 for p in plain)
+
+
+def test_chartnodes_layout_and_masks():
+    """chartnodes_create / ChartMaskFn restated (lightmap.c:723-767, 527-561): node order and skipping rules, the per-node
+    geometry against the golden-pinned function, charts moved to the origin with a 2-texel margin, mask = texels within
+    one texel of a triangle (checked against a float64 point-triangle distance away from the threshold)"""
+    import ctypes as C
+    from tests import prepare_util as pu
+    lib = load_oracle()
+    dr = pu.draw_table(count=9, seed=2)
+    tpu = 3.0
+    nodes = pu.oracle_chartnodes(lib, dr, tpu)
+    hook = lib.orc_hook_lm_chartnode; hook.restype = None
+    inp = np.zeros(10, np.float32); out = np.zeros(11, np.uint32)
+    k = 0
+    for e, m in enumerate(dr.mesh_ids):
+        if m < 0 or dr.materials[e].flags & (2 | 16):                         # MatFlag_Sky | MatFlag_Lava, lightmap.c:38
+            continue
+        P = dr.mesh_arrays[m][0]
+        M = dr.matrices[e].reshape(4, 4)                                       # M[c] = column c
+        for t in range(P.shape[0] // 3):
+            n = nodes[k]; k += 1
+            assert n["drawableIndex"] == e and n["vertIndex"] == t * 3
+            if t % 7 == 0:
+                W = [sum(np.float32(0) + M[c][:3] * P[t * 3 + v][c] for c in range(3)) for v in range(3)]   # not the bit-exact order: geometry only
+                assert abs(n["area"] - 0.5 * np.linalg.norm(np.cross(W[1] - W[0], W[2] - W[0]))) < 1e-3 * max(1.0, n["area"])
+    assert k == nodes.shape[0] and k > 20
+    # per-node geometry = the pinned function on the world-space corners (recomputed by the oracle's own flatten of the entity)
+    first = pu.chart_partition(nodes.shape[0])
+    before = nodes.copy()
+    areas, sizes, offsets, masks = pu.oracle_chart_masks(lib, nodes, first)
+    for c in range(first.shape[0] - 1):
+        tri = nodes["triCoord"][first[c]:first[c + 1]].reshape(-1, 2)
+        old = before["triCoord"][first[c]:first[c + 1]].reshape(-1, 2)
+        assert np.allclose(tri.min(0), 2.0, atol=1e-3) and np.allclose(tri - old, (tri - old)[0], atol=1e-3)
+        assert tuple(sizes[c]) == tuple((tri.max(0) + np.float32(2.0)).astype(np.int32))
+        ext = tri.max(0) - tri.min(0)
+        assert areas[c] == np.float32(ext[0]) * np.float32(ext[1])
+        sx, sy = sizes[c]
+        mask = masks[offsets[c]:offsets[c] + sx * sy].reshape(sy, sx)
+        assert set(np.unique(mask)) <= {0, 255}
+        if c % 5 == 0:                                                         # float64 distance, away from the threshold
+            ys, xs = np.meshgrid(np.arange(sy) + 0.5, np.arange(sx) + 0.5, indexing="ij")
+            dist = np.full((sy, sx), 1e9)
+            for t in nodes["triCoord"][first[c]:first[c + 1]].astype(np.float64):
+                dist = np.minimum(dist, _tri_dist(t.reshape(3, 2), xs, ys))
+            assert (mask[dist < 0.95] == 255).all() and (mask[dist > 1.05] == 0).all()
+    assert 0.005 < (masks == 255).mean() < 0.95
+
+
+def _tri_dist(t, xs, ys):
+    """signed distance to a 2D triangle (negative inside), float64"""
+    P = np.stack([xs, ys], -1)
+    d = np.full(xs.shape, 1e18); inside = np.ones(xs.shape, bool)
+    area = (t[1][0] - t[0][0]) * (t[2][1] - t[0][1]) - (t[1][1] - t[0][1]) * (t[2][0] - t[0][0])
+    for i in range(3):
+        a, b = t[i], t[(i + 1) % 3]
+        ab = b - a
+        h = np.clip(((P - a) @ ab) / max(ab @ ab, 1e-30), 0, 1)
+        d = np.minimum(d, np.linalg.norm(P - a - h[..., None] * ab, axis=-1))
+        cr = ab[0] * (P[..., 1] - a[1]) - ab[1] * (P[..., 0] - a[0])
+        inside &= (cr * np.sign(area) >= 0)
+    return np.where(inside, -d, d)
