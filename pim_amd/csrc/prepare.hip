@@ -658,8 +658,13 @@ int pimgpu_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartF
     const int blocks = (int)std::min<int64_t>(((int64_t)nodeCount + 3) / 4, (int64_t)g_lib.cuCount * 64);
     k_chart_masks<<<blocks, 256, 0, st>>>(a);
     PT_HIP(hipGetLastError());
-    /* charts' masks may be laid out with gaps: copy back chart by chart what the call owns */
-    for (int32_t c = 0; c < chartCount; ++c)
+    /* masks packed one after the other (the usual layout) come back in one copy; a layout with gaps chart by chart, so
+     * that only the bytes the call owns are written */
+    bool packed = maskOffsets[0] == 0;
+    for (int32_t c = 1; c < chartCount && packed; ++c)
+        packed = maskOffsets[c] == maskOffsets[c - 1] + (int64_t)maskSizes[2 * (c - 1)] * maskSizes[2 * (c - 1) + 1];
+    if (packed) PT_HIP(hipMemcpyAsync(masks, maskBuf.p, (size_t)total, hipMemcpyDeviceToHost, st));
+    else for (int32_t c = 0; c < chartCount; ++c)
     {
         const size_t bytes = (size_t)maskSizes[2 * c] * (size_t)maskSizes[2 * c + 1];
         if (bytes) PT_HIP(hipMemcpyAsync(masks + maskOffsets[c], (uint8_t*)maskBuf.p + maskOffsets[c], bytes, hipMemcpyDeviceToHost, st));
