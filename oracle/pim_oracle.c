@@ -1888,7 +1888,7 @@ void orc_test_dist_update(float* pdf, float* cdf, uint32_t* live, int32_t len, u
 /* ------------------------------------------------------------------------------------------ */
 /* EmbedAttributes, rendering/lightmap.c:941-1045                                              */
 
-typedef struct { const PimDrawables* d; const int32_t* pageTexIds; PimLightmapPage* pages; int32_t lmSize; } EmbedTask;
+typedef struct { const PimDrawables* d; const int32_t* pageTexIds; PimLightmapPage* pages; int32_t lmSize; const int64_t* items; } EmbedTask;
 
 static void embed_fn(void* user, int64_t begin, int64_t end, int tid)
 {
@@ -1898,8 +1898,9 @@ static void embed_fn(void* user, int64_t begin, int64_t end, int tid)
     const int32_t lmSize = t->lmSize;
     const int64_t lmLen = (int64_t)lmSize * lmSize;
     const float texelSize = (float)lmSize;
-    for (int64_t iWork = begin; iWork < end; ++iWork)                       /* :960-1031 */
+    for (int64_t iItem = begin; iItem < end; ++iItem)                       /* :960-1031 */
     {
+        const int64_t iWork = t->items ? t->items[iItem] : iItem;
         const int32_t iLightmap = (int32_t)(iWork / lmLen);
         const int32_t iTexel = (int32_t)(iWork % lmLen);
         const int32_t x = iTexel % lmSize, y = iTexel / lmSize;
@@ -1956,8 +1957,17 @@ static void embed_fn(void* user, int64_t begin, int64_t end, int tid)
 void orc_lightmap_embed(const PimDrawables* drawables, const int32_t* pageTexIds, PimLightmapPage* pages,
     int32_t lmCount, int32_t lmSize, int threads)
 {
-    EmbedTask t = { drawables, pageTexIds, pages, lmSize };
+    EmbedTask t = { drawables, pageTexIds, pages, lmSize, NULL };
     orc_parallel_for(embed_fn, &t, (int64_t)lmCount * lmSize * lmSize, threads);
+}
+
+/* the same loop body for a LIST of work items (iLightmap * lmSize^2 + iTexel) only: spot checks at sizes where the
+ * whole O(texels x triangles) loop would take hours */
+void orc_lightmap_embed_items(const PimDrawables* drawables, const int32_t* pageTexIds, PimLightmapPage* pages,
+    int32_t lmSize, const int64_t* items, int64_t itemCount, int threads)
+{
+    EmbedTask t = { drawables, pageTexIds, pages, lmSize, items };
+    orc_parallel_for(embed_fn, &t, itemCount, threads);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -85,3 +85,35 @@ def test_1m_scene_image_bit_exact(big):
     for k in ("live", "pdf", "cdf"):
         assert_bits_equal(gl[k], ol[k], k)
     t.close()
+
+
+def test_embed_full_size_pages_spot_checked_and_idempotent():
+    """EmbedAttributes at bake scale (2 pages of 1024^2, 120 k mapped triangles): the oracle's per-texel loop on 3000 texels
+    picked at random and on every texel of two rows, bit for bit; sampleCounts is 0 or 1; a second call gives the same pages"""
+    import ctypes as C
+    from tests import prepare_util as pu
+    from tests.util import load_oracle
+    gpu_init()
+    S, count = 1024, 2
+    dr = pu.embed_table(S, [0, 1], tris_per_mesh=(50_000, 70_000), chart_texels=(3.0, 30.0), hard_cases=False, seed=21)
+    pages = api.lightmap_embed(dr, pu.new_pages(count, S, fill=-3.0), S)
+    again = api.lightmap_embed(dr, pu.new_pages(count, S, fill=-3.0), S)
+    rng = np.random.default_rng(4)
+    items = np.concatenate([rng.integers(0, count * S * S, 3000), np.arange(517 * S, 518 * S), S * S + np.arange(3 * S, 4 * S)]).astype(np.int64)
+    want = pu.new_pages(count, S, fill=-3.0)
+    lib = load_oracle(True)
+    lib.orc_lightmap_embed_items.restype = None
+    lib.orc_lightmap_embed_items(C.byref(dr.desc), None, api._page_array(want, S), C.c_int32(S), items.ctypes.data_as(C.c_void_p),
+                                 C.c_int64(items.shape[0]), C.c_int(16))
+    covered = 0
+    for i in range(count):
+        g, a, w = pu.page_parts(pages[i], S), pu.page_parts(again[i], S), pu.page_parts(want[i], S)
+        sel = items[(items // (S * S)) == i] % (S * S)
+        for k, what in ((1, "position"), (2, "normal"), (3, "sampleCounts")):
+            assert_bits_equal(np.ascontiguousarray(g[k][sel]), np.ascontiguousarray(w[k][sel]), f"page {i} {what}")
+            assert (g[k].view(np.uint32) == a[k].view(np.uint32)).all()
+        assert (g[0] == -3.0).all() and set(np.unique(g[3])) <= {0.0, 1.0}
+        nrm = np.linalg.norm(g[2][g[3] > 0], axis=1)
+        assert np.abs(nrm - 1.0).max() < 1e-3
+        covered += int(w[3][sel].sum())
+    assert covered > 500
