@@ -879,7 +879,7 @@ __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ ter
  * header), so a stale history is harmless; PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
  */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 12));      /* tuning knobs, not API */
+static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 6));      /* tuning knobs, not API */
 static const int kTailWavesPerCu = std::max(1, env_int("PIMGPU_TAIL_WAVES", 8));
 
 static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)

@@ -47,7 +47,7 @@ def test_tail_refractive_sky_media_and_roulette_bit_exact(tail_env, switch):
 
 
 def test_tail_policy_uses_the_previous_call(tail_env):
-    """without the override the host switches where the previous call's queue fell below 1/12 of the batch: the first
+    """without the override the host switches where the previous call's queue fell below 1/6 of the batch: the first
     call runs every bounce as a wavefront, later calls hand the deep bounces to the tail kernel -- same bits either way"""
     os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
     gpu_init()
