@@ -743,9 +743,6 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
  * the path-state arrays exactly as between the wavefront's launches, and every path owns its Prng stream, so where
  * the switch happens does not change a bit of the result (tested for every switch point).
  */
-#ifndef PT_TAIL_OCC
-#define PT_TAIL_OCC 1                          /* waves per SIMD the register budget is sized for */
-#endif
 static constexpr int kTailThreads = 64;       /* one wave per block: the scheduler balances the uneven paths wave by wave */
 
 /*
@@ -754,7 +751,8 @@ static constexpr int kTailThreads = 64;       /* one wave per block: the schedul
  * the longest path of its wave ends.  The host launches no more waves than the machine holds at this kernel's
  * occupancy; every lane leaves once the cursor has passed the queue's end, so the grid drains.
  */
-__global__ __launch_bounds__(kTailThreads, PT_TAIL_OCC) void k_tail(DScene s, StageArgs a)
+template <int OCC>
+__global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs a)
 {
     const int32_t count = a.counters[a.inSel];
     uint32_t ext = 0, shadow = 0, other = 0; bool overflow = false;
@@ -880,7 +878,12 @@ __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ ter
  */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 6));      /* tuning knobs, not API */
-static const int kTailWavesPerCu = std::max(1, env_int("PIMGPU_TAIL_WAVES", 8));
+static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /* 0: 8 or 16 with the build below */
+/* Two builds of k_tail: 208 VGPRs (2 waves per SIMD) and <= 128 VGPRs with spills (4 per SIMD).  A tree that lives in L2
+ * leaves little latency to hide and the spills cost more than the extra waves give (Cornell 2.22 against 2.29 ms); a
+ * tree served from the Infinity Cache is the other way round (1 M triangles 7.52 against 7.13 ms).  The host picks by
+ * the size of the tree. */
+static constexpr int64_t kTailDenseTreeBytes = 8ll << 20;
 
 static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
@@ -971,9 +974,14 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
              * the machine holds at k_tail's occupancy (2 per SIMD): lanes take further paths as theirs end */
             const int64_t expect = (g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n;
             a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
-            const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * kTailWavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
+            const int64_t treeBytes = 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount;
+            const int forceDense = env_int("PIMGPU_TAIL_DENSE", -1);            /* -1: by tree size; 0 / 1 force (tests) */
+            const bool dense = forceDense >= 0 ? forceDense != 0 : treeBytes > kTailDenseTreeBytes;
+            const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 8);
+            const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * wavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
             const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
-            k_tail<<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
+            if (dense) k_tail<4><<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
+            else k_tail<1><<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
         }

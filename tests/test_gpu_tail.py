@@ -14,7 +14,7 @@ from tests.test_gpu_image import _render_both
 pytestmark = pytest.mark.gpu
 
 
-KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS")
+KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_DENSE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS")
 
 
 @pytest.fixture
@@ -91,5 +91,15 @@ def test_image_shares_on_concurrent_streams_bit_exact(tail_env, groups, stagger,
     os.environ["PIMGPU_GROUP_MIN_PATHS"] = "64"
     os.environ["PIMGPU_TAIL_BOUNCE"] = switch
     _render_both(scenes.cornell_box(), 128, 72, 3, 8)
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
+
+
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_both_builds_of_the_tail_kernel_bit_exact(tail_env, dense):
+    """k_tail exists twice (2 or 4 waves per SIMD, picked by the size of the tree): either build, the oracle's bits"""
+    os.environ["PIMGPU_TAIL_DENSE"] = dense
+    os.environ["PIMGPU_TAIL_BOUNCE"] = "1"
+    _render_both(scenes.cornell_box(), 128, 72, 2, 8)
     sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
     _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
