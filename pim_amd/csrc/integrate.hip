@@ -498,6 +498,11 @@ __device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a
         return out;
 }
 
+/* SLOW builds: the place of a thread in its block's share of the short list.  Entry e of the list goes to block e % grid
+ * and there to rank e / grid; ranks go to the block's WAVES first (rank r -> wave r % 8, lane r / 8), so that a block's few
+ * heavy paths sit in eight waves side by side instead of sharing the first one */
+__device__ __forceinline__ uint32_t slow_rank() { return (threadIdx.x >> 6) + (kShadeThreads / 64) * (threadIdx.x & 63); }
+
 /* the traversal stack of a kernel's inline rays: lane-interleaved LDS words + the spill area behind them (traverse.h) */
 __device__ __forceinline__ LdsStack kernel_stack(unsigned long long* shared, const StageArgs& a)
 {
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
      * heavy paths run on every CU at once, a few lanes per wave, instead of filling the waves of two blocks */
     for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;
+        const int32_t idx = SLOW ? base + (int32_t)(slow_rank() * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;
         bool deferred = false;
         int32_t pos = 0;
         if (idx < count)
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
     uint32_t other = 0; bool overflow = false;
     for (int32_t base = SLOW ? 0 : blockIdx.x * kShadeThreads; base < count; base += gridDim.x * kShadeThreads)
     {
-        const int32_t idx = SLOW ? base + (int32_t)(threadIdx.x * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;   /* as in shade_a */
+        const int32_t idx = SLOW ? base + (int32_t)(slow_rank() * gridDim.x + blockIdx.x) : base + (int32_t)threadIdx.x;   /* as in shade_a */
         bool alive = false, deferred = false;
         int32_t slot = 0, pos = 0;
         v4 ro = f4_s(0.0f), rd = f4_s(0.0f);
