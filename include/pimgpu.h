@@ -215,7 +215,7 @@ void pimgpu_host_free(void* p);
 /* the hipStream_t every call of the library runs on (for HIP events around a call: bench.py's roofline leg) */
 void* pimgpu_stream(void);
 /* measurement aid (no counterpart in the reference): with enable != 0 every closest-hit launch runs the COUNTING
- * build of the traversal kernel, which adds up the BVH nodes it fetches (128 B each), the triangles it tests (48 B
+ * build of the traversal kernel, which adds up the BVH nodes it fetches (64 B each: the compressed nodes), the triangles it tests (48 B
  * each) and the rays it traces.  out (may be NULL) receives {nodes, triangles, rays, most nodes of one ray} since the last call;
  * the counters are then cleared.  These are the per-ray figures of the roofline's algorithmic bytes. */
 int pimgpu_work_counters(int enable, uint64_t* out);

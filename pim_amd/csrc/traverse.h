@@ -277,7 +277,7 @@ struct LdsStack
  * ANY = false: closest hit (see contract above).  ANY = true: returns at the first accepted hit.
  * overflow: set to true when the stack was full and a subtree had to be dropped (the caller reports it).
  */
-/* per-lane work counters of the measurement build (COUNT = true): nodes fetched (128 B each), triangles tested (48 B each) */
+/* per-lane work counters of the measurement build (COUNT = true): nodes fetched (64 B each, the compressed copy), triangles tested (48 B each) */
 struct TraverseCounts { uint32_t nodes, tris; };
 
 template <bool ANY, class Stack, bool COUNT = false>
