@@ -39,6 +39,7 @@ struct TraceResources
     unsigned long long* work = nullptr;  /* device: nodes fetched, triangles tested, rays (counting build of the kernel) */
     bool counting = false;               /* pimgpu_work_counters(1, ..): launch the counting build */
     int32_t gridBlocks = 0;
+    int chunkParity = 0;                 /* which of the two ray-chunk counters (status words 24, 25) the next launch uses */
     int ensure();
     void release();
 };

@@ -48,7 +48,8 @@ static constexpr int kTraceBlocksPerCU = 8;
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
-    unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work)
+    unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work,
+    uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk)
 {
     __shared__ unsigned long long sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
@@ -64,9 +65,17 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     /* this wave's slice of the rays: contiguous, a multiple of 64 long */
     const int32_t wavesTotal = (int32_t)gridDim.x * (kTraceThreads / 64);
     const int32_t wave = (int32_t)blockIdx.x * (kTraceThreads / 64) + (int32_t)(threadIdx.x >> 6);
-    const int64_t per = ((((int64_t)n + wavesTotal - 1) / wavesTotal) + 63) & ~(int64_t)63;
+    /* dynChunk == 0: one static slice per wave (contiguous, a multiple of 64 long).  dynChunk > 0: rays in chunks -- the
+     * first chunk of a wave is its own, further ones come from a counter (one returning atomic per chunk), so that waves
+     * whose rays were short take over rays of the others.  That pays when rays are long (a tree served from the Infinity
+     * Cache: 1 M-triangle scene 7.10 -> 6.90 ms per sample) and costs when they are short and the counter becomes the
+     * bottleneck (Cornell 2.23 -> 2.88 ms): the host decides (trace_chunk).  The launch zeroes the counter of the NEXT
+     * launch (the previous launch, which used that one, has finished: same stream). */
+    if (blockIdx.x == 0 && threadIdx.x == 0) *chunkCounterNext = 0u;
+    const int64_t per = dynChunk > 0 ? (int64_t)dynChunk : ((((int64_t)n + wavesTotal - 1) / wavesTotal) + 63) & ~(int64_t)63;
     int32_t cursor = (int32_t)min((int64_t)n, per * wave);
-    const int32_t sliceEnd = (int32_t)min((int64_t)n, per * (wave + 1));
+    int32_t sliceEnd = (int32_t)min((int64_t)n, per * (wave + 1));
+    bool moreGlobal = dynChunk > 0 && per * wavesTotal < (int64_t)n;
 
     const float4* __restrict__ nodes = bvh.nodes;
     const uint4* __restrict__ cnodes = bvh.cnodes;
@@ -84,6 +93,14 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     {
         /* refill idle lanes with the next rays of the slice */
         {
+            if (cursor >= sliceEnd && moreGlobal)
+            {
+                uint32_t got = 0;
+                if ((threadIdx.x & 63) == 0) got = atomicAdd(chunkCounter, (uint32_t)dynChunk);
+                const int64_t base = (int64_t)__builtin_amdgcn_readfirstlane(got) + per * wavesTotal;
+                if (base >= (int64_t)n) moreGlobal = false;
+                else { cursor = (int32_t)base; sliceEnd = (int32_t)min((int64_t)n, base + per); }
+            }
             const unsigned long long idle = __ballot(!active);
             if (cursor < sliceEnd && idle != 0ull)
             {
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
             }
             if (__ballot(active) == 0ull)
             {
-                if (cursor >= sliceEnd) break;
+                if (cursor >= sliceEnd && !moreGlobal) break;
                 continue;
             }
         }
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
                 active = false;             /* the record is stored at the next refill */
             }
             const int32_t idleCount = (int32_t)__popcll(__ballot(!active));
-            if (idleCount == 64 || (idleCount >= PT_REFILL_IDLE && cursor < sliceEnd)) break;
+            if (idleCount == 64 || (idleCount >= PT_REFILL_IDLE && (cursor < sliceEnd || moreGlobal))) break;
         }
         /* store the records of the rays that finished during this round of trips: the two barycentric divisions and the store
          * run here, once per batch of finished lanes, not on every trip on which some lane finishes */
@@ -267,6 +284,14 @@ void TraceResources::release()
     spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
+/* rays per dynamic chunk, 0 = static slices (k_trace's header): by the size of the tree, like the tail kernel's build */
+static int32_t trace_chunk(const DBvh& bvh)
+{
+    static const int forced = [] { const char* e = getenv("PIMGPU_TRACE_CHUNK"); return (e && *e) ? atoi(e) : -1; }();
+    if (forced >= 0) return forced & ~63;
+    return (64ll * bvh.nodeCount + 48ll * bvh.triCount > (8ll << 20)) ? 64 : 0;
+}
+
 /* t0 / t1 (optional): events attached to the dispatch itself (hipExtLaunchKernelGGL): they time the kernel from its own
  * completion signal.  Separate hipEventRecord calls around the launch put two barrier packets into the queue, ~6 us of
  * idle GPU each -- 12 per Cornell sample. */
@@ -277,15 +302,17 @@ int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, cons
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
     int32_t* noOccluded = nullptr;
+    uint32_t* cc = res->status + 24 + res->chunkParity; uint32_t* cn = res->status + 24 + (res->chunkParity ^ 1); res->chunkParity ^= 1;
+    const int32_t dc = trace_chunk(bvh);
     if (res->counting)
     {
         if (t0) hipEventRecord(t0, stream);
-        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
+        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
         if (t1) hipEventRecord(t1, stream);
     }
     else if (t0 && t1) hipExtLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
-        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work);
-    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work);
+        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
+    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }
@@ -296,7 +323,9 @@ int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const fl
     if (n <= 0) return PIMGPU_OK;
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
-    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work);
+    uint32_t* cc = res->status + 24 + res->chunkParity; uint32_t* cn = res->status + 24 + (res->chunkParity ^ 1); res->chunkParity ^= 1;
+    const int32_t dc = trace_chunk(bvh);
+    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work, cc, cn, dc);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }
