@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     /* this wave's slice of the rays: contiguous, a multiple of 64 long */
     const int32_t wavesTotal = (int32_t)gridDim.x * (kTraceThreads / 64);
     const int32_t wave = (int32_t)blockIdx.x * (kTraceThreads / 64) + (int32_t)(threadIdx.x >> 6);
-    /* dynChunk == 0: one static slice per wave (contiguous, a multiple of 64 long).  dynChunk > 0: rays in chunks -- the
+    /* dynChunk == 0: one static slice per wave (contiguous, a multiple of 64 long).  dynChunk > 0 (the host uses 128): rays in chunks -- the
      * first chunk of a wave is its own, further ones come from a counter (one returning atomic per chunk), so that waves
      * whose rays were short take over rays of the others.  That pays when rays are long (a tree served from the Infinity
      * Cache: 1 M-triangle scene 7.10 -> 6.90 ms per sample) and costs when they are short and the counter becomes the
@@ -289,7 +289,7 @@ static int32_t trace_chunk(const DBvh& bvh)
 {
     static const int forced = [] { const char* e = getenv("PIMGPU_TRACE_CHUNK"); return (e && *e) ? atoi(e) : -1; }();
     if (forced >= 0) return forced & ~63;
-    return (64ll * bvh.nodeCount + 48ll * bvh.triCount > (8ll << 20)) ? 64 : 0;
+    return (64ll * bvh.nodeCount + 48ll * bvh.triCount > (8ll << 20)) ? 128 : 0;
 }
 
 /* t0 / t1 (optional): events attached to the dispatch itself (hipExtLaunchKernelGGL): they time the kernel from its own
