@@ -1539,6 +1539,7 @@ void orc_raygen(OrcScene* s, const float* origin, int32_t count, uint32_t sample
     RaysTask t; memset(&t, 0, sizeof(t));
     t.s = s; t.sampleIndex = sampleIndex; t.seed = seed; t.maxBounces = maxBounces;
     t.origin = o4(origin[0], origin[1], origin[2], origin[3]); t.colors = colors; t.directions = directions;
+    orc_scene_update_dists(s);          /* Pt_RayGen: PtScene_Update first (pt.c:2625 -> :1034 UpdateDists); AmbCube_Bake comes through here */
     orc_parallel_for(rays_fn, &t, count, threads);
 }
 

@@ -130,6 +130,7 @@ struct StageArgs
     int32_t* slowA; int32_t* slowB; /* queue positions the FAST builds deferred (lengths: counters[2], counters[3]) */
     int32_t tailLanes;              /* k_tail: lanes of each wave that take paths */
     unsigned long long* spill;      /* k_tail: overflow area of the traversal stacks (TraceResources::spill) */
+    int32_t stackCap;               /* entries a traversal stack may hold (trace_stack_cap) */
 };
 
 __device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
@@ -510,7 +511,7 @@ __device__ __forceinline__ LdsStack kernel_stack(unsigned long long* shared, con
     st.lds = (lds_u64*)(shared + threadIdx.x); st.ldsStride = (int)blockDim.x;
     st.spillStride = (int64_t)gridDim.x * blockDim.x;
     st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x));
-    st.sp = 0;
+    st.sp = 0; st.cap = a.stackCap;
     return st;
 }
 
@@ -771,6 +772,7 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
     st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = kTailThreads;
     st.spillStride = (int64_t)gridDim.x * kTailThreads;
     st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * kTailThreads + threadIdx.x));
+    st.cap = a.stackCap;
     for (;;)
     {
         if ((int32_t)(threadIdx.x & 63) >= a.tailLanes) break;
@@ -971,7 +973,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         a.extO = w.extO[in] + first; a.extD = w.extD[in] + first; a.extHit = w.extHit + first; a.neeHit = w.neeHit + first;
         a.neeO = w.neeO + first; a.neeD = w.neeD + first;
         a.extOOut = w.extO[out] + first; a.extDOut = w.extD[out] + first; a.results = w.results; a.stats = g.stats;
-        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = g.trace->spill;
+        a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = g.trace->spill; a.stackCap = trace_stack_cap();
         if (b >= tailBounce)
         {
             /* the queue is short by now (or the caller forced it): one launch finishes every path.
@@ -1017,11 +1019,17 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     int32_t counts[64];
     PT_HIP(hipMemcpyAsync(hs, g.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
     PT_HIP(hipMemcpyAsync(counts, g.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
+    /* the batched traversal launches report a full stack in their own status word (trace.hip), the stages and the tail
+     * kernel in stats[4]: both end the call with PIMGPU_E_LIMIT, and the word is cleared so that it cannot be blamed on
+     * the next intersect call */
+    uint32_t traceStatus = 0;
+    PT_HIP(hipMemcpyAsync(&traceStatus, g.trace->status, sizeof(traceStatus), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
+    if (traceStatus & 1u) { PT_HIP(hipMemsetAsync(g.trace->status, 0, 4, st)); hs[4] |= 1ull; }
     float traceMs = 0.0f;
     for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; }
     g.events.clear();
-    if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow"); return PIMGPU_E_LIMIT; }
+    if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow (tree deeper than %d entries)", PT_STACK_MAX); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
      * what the history knew beyond its switch point. */
     if (g.historyN != g.n) { g.historyN = g.n; g.historyBounces = 0; }
@@ -1292,6 +1300,8 @@ static int trace_rays_common(PimScene* scene, const float* ro, const float* rd, 
     {
         if (hipMalloc(&dirDev, sizeof(float4) * (size_t)n) != hipSuccess) { set_error("raygen: out of device memory"); return PIMGPU_E_NOMEM; }
         org = f4_v(origin[0], origin[1], origin[2], origin[3]);
+        /* Pt_RayGen starts with PtScene_Update (pt.c:2625), which reaches UpdateDists (:1034); Pt_TraceRay alone does not */
+        if ((rc = update_dists(scene->d, st))) { cleanup(); return rc; }
     }
     k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], roDev, rdDev, org, dirDev, n, sampleIndex, seed, 0);
     rc = integrate_paths(scene, n, maxBounces, nullptr, nullptr);
@@ -1372,6 +1382,7 @@ int pimgpu_ambcube_bake(PimScene* scene, float* cube, const float* origin, int32
         if (hipMalloc(&dirDev, sizeof(float4) * (size_t)samples) != hipSuccess || hipMalloc(&cubeDev, sizeof(float4) * 6) != hipSuccess)
         { hipFree(dirDev); set_error("ambcube_bake: out of device memory"); return PIMGPU_E_NOMEM; }
         hipMemcpyAsync(cubeDev, cube, sizeof(float4) * 6, hipMemcpyHostToDevice, st);
+        if ((rc = update_dists(scene->d, st))) { hipFree(dirDev); hipFree(cubeDev); return rc; }     /* AmbCube_Bake -> Pt_RayGen -> PtScene_Update, pt.c:2625 */
         k_init_rays<<<(samples + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], nullptr, nullptr,
             f4_v(origin[0], origin[1], origin[2], origin[3]), dirDev, samples, sampleIndex, seed, 0);
         rc = integrate_paths(scene, samples, maxBounces, nullptr, nullptr);

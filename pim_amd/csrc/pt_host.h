@@ -43,6 +43,9 @@ struct TraceResources
     int ensure();
     void release();
 };
+/* entries a traversal stack may hold before the kernels report overflow: PT_STACK_MAX; PIMGPU_STACK_CAP (tests only)
+ * lowers it, never below the LDS part.  Read per launch. */
+int32_t trace_stack_cap();
 
 /* trace.hip */
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,

@@ -132,7 +132,7 @@ __device__ __forceinline__ int32_t hit_type(const DScene& s, v4 rd, DHit h) { re
 struct Ctx { u4 rng; uint32_t shadowRays, otherRays; bool overflow; bool defer; LdsStack stack; /* SLOW builds: the calling kernel's traversal stack */ };
 __device__ __forceinline__ float Sample1D(Ctx& c) { return rng_f32(&c.rng); }      /* pt.c:377 */
 __device__ __forceinline__ v2 Sample2D(Ctx& c) { return rng_f2(&c.rng); }          /* pt.c:382 */
-__device__ __forceinline__ Ctx ctx_make() { Ctx c; c.rng.x = c.rng.y = c.rng.z = c.rng.w = 0; c.shadowRays = c.otherRays = 0; c.overflow = false; c.defer = false; c.stack.lds = nullptr; c.stack.spill = nullptr; c.stack.ldsStride = 0; c.stack.spillStride = 0; c.stack.sp = 0; return c; }
+__device__ __forceinline__ Ctx ctx_make() { Ctx c; c.rng.x = c.rng.y = c.rng.z = c.rng.w = 0; c.shadowRays = c.otherRays = 0; c.overflow = false; c.defer = false; c.stack.lds = nullptr; c.stack.spill = nullptr; c.stack.ldsStride = 0; c.stack.spillStride = 0; c.stack.sp = 0; c.stack.cap = PT_STACK_MAX; return c; }
 
 /* a closest-hit query traced inline by the calling lane (rare rays: media NEE, refraction thickness; SLOW builds only) */
 __device__ __forceinline__ RayHit intersect_inline(Ctx& ctx, const DScene& s, v4 ro, v4 rd, float tNear, float tFar)

@@ -51,7 +51,7 @@ int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float*
 /* RtcPointQuery (path_tracer.c:555-616): distance to the nearest triangle inside the query radius,
  * kRcpEpsilon when there is none.  BVH walk with a fixed, slightly enlarged pruning radius; the
  * minimum over the surviving triangles does not depend on the visiting order. */
-__device__ float point_query_distance(const DScene& s, v4 pt)
+__device__ float point_query_distance(const DScene& s, v4 pt, bool* overflow)
 {
     const float radius = pt.w;
     const float prune = radius * 1.001f + 1e-6f;
@@ -74,7 +74,11 @@ __device__ float point_query_distance(const DScene& s, v4 pt)
                 const float ex = fmaxf(fmaxf(lx[k] - pt.x, pt.x - hx[k]), 0.0f);
                 const float ey = fmaxf(fmaxf(ly[k] - pt.y, pt.y - hy[k]), 0.0f);
                 const float ez = fmaxf(fmaxf(lz[k] - pt.z, pt.z - hz[k]), 0.0f);
-                if (ex * ex + ey * ey + ez * ez <= prune2 && sp < PT_STACK_MAX) stack[sp++] = c[k];
+                if (ex * ex + ey * ey + ez * ez <= prune2)
+                {
+                    if (sp < PT_STACK_MAX) stack[sp++] = c[k];
+                    else *overflow = true;          /* a dropped subtree could hold the nearest triangle: reported, scene_create fails */
+                }
             }
         }
         else
@@ -116,6 +120,7 @@ struct GridArgs
     float4* rayO; float4* rayD;              /* probe rays: [cell][16]; shadow rays: [cell][E][16] */
     DHit* hits; int32_t* occluded;
     uint8_t* state;                          /* per cell of the chunk: 0 culled, 1 needs the probe verdict, 2 alive */
+    uint32_t* status;                        /* TraceResources::status: bit 0 = a traversal stack overflowed */
 };
 
 __device__ __forceinline__ v4 grid_cell_position(const DScene& s, int32_t iCell, float radius)
@@ -133,7 +138,9 @@ __global__ __launch_bounds__(64) void k_grid_probe(DScene s, GridArgs g)
     const float radius = g.metersPerCell * 0.666f;
     g.cellLength[iCell] = 0;
     const v4 position = grid_cell_position(s, iCell, radius);
-    const float qd = point_query_distance(s, position);
+    bool overflow = false;
+    const float qd = point_query_distance(s, position, &overflow);
+    if (overflow) atomicOr(g.status, 1u);
     const bool probe = qd > radius;
     g.state[c] = probe ? 1 : 2;
     for (int j = 0; j < 16; ++j)
@@ -230,7 +237,7 @@ int setup_light_grid(const DScene& s, TraceResources* res, float metersPerCell, 
     {
         GridArgs g;
         g.metersPerCell = metersPerCell; g.seed = seed; g.cellFirst = first; g.cellCount = std::min(chunk, s.gridLen - first);
-        g.cellLength = cellLengthDev; g.rayO = rayO; g.rayD = rayD; g.hits = hits; g.occluded = (int32_t*)hits; g.state = state;
+        g.cellLength = cellLengthDev; g.rayO = rayO; g.rayD = rayD; g.hits = hits; g.occluded = (int32_t*)hits; g.state = state; g.status = res->status;
         const int blocks = (g.cellCount + 63) / 64;
         k_grid_probe<<<blocks, 64, 0, stream>>>(s, g);
         if ((rc = trace_closest(s.bvh, res, rayO, rayD, hits, g.cellCount * 16, nullptr, stream))) break;

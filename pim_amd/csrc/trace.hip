@@ -49,7 +49,7 @@ template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
     unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work,
-    uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk)
+    uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk, int32_t stackCap)
 {
     __shared__ unsigned long long sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4*
     st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = kTraceThreads;
     st.spillStride = (int64_t)gridDim.x * kTraceThreads;
     st.spill = (glb_u64*)(spill + ((int64_t)blockIdx.x * kTraceThreads + threadIdx.x));
-    st.init();
+    st.init(); st.cap = stackCap;
     bool overflow = false;
     uint32_t cNodes = 0, cTris = 0, cRays = 0, cWorst = 0, rayNodes = 0;
     uint32_t cTrips = 0, cExecA = 0, cExecB = 0, cPopIter = 0, cPopLanes = 0;     /* counting build: wave-level executions of each section */
@@ -284,6 +284,13 @@ void TraceResources::release()
     spill = nullptr; status = nullptr; gridBlocks = 0;
 }
 
+int32_t trace_stack_cap()
+{
+    const char* e = getenv("PIMGPU_STACK_CAP");
+    if (!e || !*e) return PT_STACK_MAX;
+    return std::max(PT_STACK_LDS, std::min(PT_STACK_MAX, atoi(e)));
+}
+
 /* rays per dynamic chunk, 0 = static slices (k_trace's header): by the size of the tree, like the tail kernel's build */
 static int32_t trace_chunk(const DBvh& bvh)
 {
@@ -303,16 +310,16 @@ int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, cons
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
     int32_t* noOccluded = nullptr;
     uint32_t* cc = res->status + 24 + res->chunkParity; uint32_t* cn = res->status + 24 + (res->chunkParity ^ 1); res->chunkParity ^= 1;
-    const int32_t dc = trace_chunk(bvh);
+    const int32_t dc = trace_chunk(bvh), cap = trace_stack_cap();
     if (res->counting)
     {
         if (t0) hipEventRecord(t0, stream);
-        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
+        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
         if (t1) hipEventRecord(t1, stream);
     }
     else if (t0 && t1) hipExtLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
-        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
-    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc);
+        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
+    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }
@@ -324,8 +331,8 @@ int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const fl
     int rc = res->ensure(); if (rc) return rc;
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
     uint32_t* cc = res->status + 24 + res->chunkParity; uint32_t* cn = res->status + 24 + (res->chunkParity ^ 1); res->chunkParity ^= 1;
-    const int32_t dc = trace_chunk(bvh);
-    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work, cc, cn, dc);
+    const int32_t dc = trace_chunk(bvh), cap = trace_stack_cap();
+    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work, cc, cn, dc, cap);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }

@@ -227,11 +227,13 @@ struct LdsStack
     int ldsStride;
     int64_t spillStride;
     int sp;
+    int cap;                    /* entries the stack may hold: PT_STACK_MAX, or fewer (>= PT_STACK_LDS) when a test lowers it
+                                   (PIMGPU_STACK_CAP) to exercise the overflow report without a 64-level tree */
     __device__ __forceinline__ static unsigned long long pack(float t, int32_t c) { return ((unsigned long long)(uint32_t)c << 32) | (unsigned long long)__float_as_uint(t); }
     __device__ __forceinline__ void init() { sp = 0; }
     __device__ __forceinline__ bool push(float t, int32_t c)
     {
-        if (sp >= PT_STACK_MAX) return false;
+        if (sp >= cap) return false;
         if (sp < PT_STACK_LDS) lds[sp * ldsStride] = pack(t, c);
         else spill[(int64_t)(sp - PT_STACK_LDS) * spillStride] = pack(t, c);
         ++sp;
