@@ -340,6 +340,11 @@ int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDe
 int pimgpu_trace_copy_dev(const PimTrace* trace, void* colorDst, void* albedoDst, void* normalDst);
 /* CalcStdDev (render_system.c:1374-1394) on the device colour buffer */
 int pimgpu_trace_stddev(const PimTrace* trace, float* meanOut, float* stddevOut);
+/* NO COUNTERPART IN THE REFERENCE.  pimgpu_trace_stddev for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): same result bit for bit, but the per-pixel terms live in a
+ * file-scope device array of the library (31.6 MiB per GPU, held until the process ends) instead of a work buffer grown
+ * on demand.  Limit: width*height <= 3840*2160, else PIMGPU_E_LIMIT.  Calls that overlap on one GPU share the array and race. */
+int pimgpu_trace_stddev_noalloc(const PimTrace* trace, float* meanOut, float* stddevOut);
 /* statistics of the last pimgpu_trace_image call: rays traced (extension, shadow, other), bounces */
 typedef struct PimTraceStats
 {

@@ -116,7 +116,7 @@ EXPORTS = [
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
-    "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev",
+    "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc",
 ]
 
 _LIB = None
@@ -295,6 +295,11 @@ class Trace:
     def stddev(self):
         m, s = C.c_float(), C.c_float()
         check(self.lib.pimgpu_trace_stddev(self.handle, C.byref(m), C.byref(s)), "pimgpu_trace_stddev")
+        return m.value, s.value
+
+    def stddev_noalloc(self):
+        m, s = C.c_float(), C.c_float()
+        check(self.lib.pimgpu_trace_stddev_noalloc(self.handle, C.byref(m), C.byref(s)), "pimgpu_trace_stddev_noalloc")
         return m.value, s.value
 
     def stats(self):

@@ -148,6 +148,7 @@ int pimgpu_init(int device)
     g_lib.cuCount = prop.multiProcessorCount;
     int rc = g_lib.trace.ensure();
     if (rc) return rc;
+    if ((rc = stddev_scratch_setup(device))) return rc;
     g_lib.initialised = true;
     return PIMGPU_OK;
 }

@@ -875,6 +875,31 @@ __global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ ter
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* scratch of pimgpu_trace_stddev_noalloc: the per-pixel terms CalcStdDev's two serial sums walk over, and the two results.
+ * A file-scope device array instead of the grown-on-demand work buffer of pimgpu_trace_stddev, for callers that cannot
+ * call hipMalloc.  Every GPU holds its own copy (kStddevScratchFloats * 4 bytes = 31.6 MiB) until the process ends.  The
+ * array's NAME is a host-side stand-in, not a device address: host code only ever uses the per-device address that
+ * hipGetSymbolAddress returned at pimgpu_init (stddev_scratch_setup below). */
+static constexpr int32_t kStddevNoAllocMaxPixels = 3840 * 2160;
+static constexpr int32_t kStddevScratchHead = 64;                 /* floats in front of the terms: [0] mean, [1] stddev */
+static constexpr size_t kStddevScratchFloats = (size_t)kStddevNoAllocMaxPixels + kStddevScratchHead;
+static __device__ __align__(256) float scratch[kStddevScratchFloats];
+static constexpr int kScratchMaxDevices = 64;
+static float* g_scratchPtr[kScratchMaxDevices] = {};              /* per device: where that GPU's copy of `scratch` lives */
+
+/* once per device, with that device current (pimgpu_init) */
+int stddev_scratch_setup(int device)
+{
+    if (device < 0 || device >= kScratchMaxDevices) { set_error("device %d beyond the %d the library keeps scratch addresses for", device, kScratchMaxDevices); return PIMGPU_E_LIMIT; }
+    if (g_scratchPtr[device]) return PIMGPU_OK;
+    float* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) { set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e)); return PIMGPU_E_DEVICE; }
+    g_scratchPtr[device] = ptr;
+    return PIMGPU_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
 /* host: the bounce loop                                                                           */
 
 /*
@@ -1261,6 +1286,38 @@ int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
     k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev, 0);
     k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
     k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
+    float h[2];
+    PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    if (meanOut) *meanOut = h[0];
+    if (stddevOut) *stddevOut = h[1];
+    return PIMGPU_OK;
+}
+
+/* pimgpu_trace_stddev without any allocation: the same two kernels per sum, their terms in this GPU's copy of the
+ * file-scope `scratch` array (address taken at pimgpu_init).  No hipMalloc / hipFree / allocating routine is called.
+ * Calls that overlap on one GPU share that array and race; nothing needs clearing (terms [0, len) are all rewritten). */
+int pimgpu_trace_stddev_noalloc(const PimTrace* t, float* meanOut, float* stddevOut)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!t) { set_error("trace_stddev_noalloc: NULL trace"); return PIMGPU_E_INVALID; }
+    const int64_t len64 = (int64_t)t->width * t->height;
+    if (len64 > kStddevNoAllocMaxPixels)
+    {
+        set_error("trace_stddev_noalloc: %dx%d = %lld pixels exceed the static scratch of %d pixels (3840x2160); use pimgpu_trace_stddev",
+            t->width, t->height, (long long)len64, kStddevNoAllocMaxPixels);
+        return PIMGPU_E_LIMIT;
+    }
+    float* base = (g_lib.device >= 0 && g_lib.device < kScratchMaxDevices) ? g_scratchPtr[g_lib.device] : nullptr;
+    if (!base) { set_error("trace_stddev_noalloc: no scratch address for device %d (pimgpu_init)", g_lib.device); return PIMGPU_E_STATE; }
+    const int32_t len = (int32_t)len64;
+    float* outDev = base;
+    float* terms = base + kStddevScratchHead;
+    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, nullptr, terms);
+    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev, 0);
+    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
+    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
+    PT_HIP(hipGetLastError());
     float h[2];
     PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));

@@ -119,6 +119,7 @@ int setup_light_grid(const DScene& s, TraceResources* res, float metersPerCell, 
 int update_dists(const DScene& s, hipStream_t stream);
 
 /* integrate.hip */
+int stddev_scratch_setup(int device);      /* address of this device's copy of the no-alloc scratch array */
 int pack_rays(const float4* ro, const float4* rd, const float* tNear, const float* tFar, int32_t n, float4* rayO, float4* rayD, hipStream_t stream);
 
 } /* namespace pt */
