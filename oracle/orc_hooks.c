@@ -84,6 +84,14 @@ HOOK(UvBilinearClamp_4x4)
 }
 HOOK(Cubemap_CalcUv) { v2 uv; int f = Cubemap_CalcUv(F3(in, 0, 0.0f), &uv); out[0] = (uint32_t)f; PF(out, 1, uv.x); PF(out, 2, uv.y); }
 
+HOOK(GGXEnergyCompensation)
+{
+    float tex[32]; memcpy(tex, in, sizeof(tex));
+    v2 a = BrdfLut_Sample((const v2*)tex, 4, 4, F(in, 35), F(in, 36));
+    v4 e = GGXEnergyCompensationLut((const v2*)tex, 4, 4, F3(in, 32, 0.0f), F(in, 35), F(in, 36));
+    PF(out, 0, a.x); PF(out, 1, a.y); P3(out, 2, e);
+}
+
 HOOK(brdf_lut_sample)
 {
     const float rcp = 1.0f / (float)(int32_t)in[2], dx = 1.0f / (float)(int32_t)in[3];

@@ -604,6 +604,15 @@ ORC_INL v2 UvBilinearClamp_f2(const v2* tex, int32_t sx, int32_t sy, v2 uv)     
     orc_bilinear bi = BilinearClamp(sx, sy, uv);
     return o2_bilerp(tex[bi.a], tex[bi.b], tex[bi.c], tex[bi.d], bi.frac);
 }
+
+/* BrdfLut_Sample, math/lighting.h:52-55; GGXEnergyCompensation, :294-303 (the table is g_BrdfLut there, an argument here) */
+ORC_INL v2 BrdfLut_Sample(const v2* lut, int32_t sx, int32_t sy, float NoV, float alpha) { return UvBilinearClamp_f2(lut, sx, sy, o2(NoV, alpha)); }
+ORC_INL v4 GGXEnergyCompensationLut(const v2* lut, int32_t sx, int32_t sy, v4 f0, float NoV, float alpha)
+{
+    v2 dvf_dv = BrdfLut_Sample(lut, sx, sy, NoV, alpha);
+    float t = (1.0f / o_max(dvf_dv.y, ORC_EPS)) - 1.0f;
+    return o4_adds(o4_muls(f0, t), 1.0f);
+}
 ORC_INL v3 UvBilinearClamp_f3(const v3* tex, int32_t sx, int32_t sy, v2 uv)                       /* :337-341 */
 {
     orc_bilinear bi = BilinearClamp(sx, sy, uv);

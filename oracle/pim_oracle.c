@@ -917,9 +917,7 @@ static SurfHit GetSurface(const OrcScene* s, v4 rd, const PimRayHit* hit)   /* p
 
 static v4 GGXEnergyCompensation(const OrcScene* s, v4 f0, float NoV, float alpha)   /* lighting.h:294-303 */
 {
-    v2 dvf_dv = UvBilinearClamp_f2(s->lut, s->lutSize, s->lutSize, o2(NoV, alpha));
-    float t = (1.0f / o_max(dvf_dv.y, ORC_EPS)) - 1.0f;
-    return o4_adds(o4_muls(f0, t), 1.0f);
+    return GGXEnergyCompensationLut(s->lut, s->lutSize, s->lutSize, f0, NoV, alpha);
 }
 
 static v4 Eval_Diffuse(const SurfHit* surf, v4 I, v4 L)                     /* :1476-1497 */
@@ -1496,6 +1494,19 @@ void orc_intersect_f64(const OrcScene* s, const float* ro, const float* rd, cons
     IsectTask t; memset(&t, 0, sizeof(t));
     t.s = s; t.ro = ro; t.rd = rd; t.tNear = tNear; t.tFar = tFar; t.prim = prim; t.t64 = tOut;
     orc_parallel_for(isect64_fn, &t, n, threads);
+}
+
+/* The two ground truths on a bare triangle soup (no scene set-up: BASELINE config 5's 20 M triangles would spend minutes in
+ * SetupEmissives / SetupLightGrid, and brute force needs neither): the contract's fp32 watertight test over ALL triangles
+ * (prim, tuv; what the GPU must equal bit for bit) and, when t64 != NULL, the fp64 ground truth (prim64, t64).
+ * positions: float4[vertCount], borrowed. */
+void orc_brute_positions(const float* positions, int32_t vertCount, const float* ro, const float* rd, const float* tNear, const float* tFar,
+    int32_t n, int32_t* prim, float* tuv, int32_t* prim64, double* t64, int threads)
+{
+    OrcScene s; memset(&s, 0, sizeof(s));
+    s.positions = (v4*)positions; s.vertCount = vertCount; s.accel = 0;
+    if (prim && tuv) orc_intersect_raw(&s, ro, rd, tNear, tFar, n, prim, tuv, 1, threads);
+    if (prim64 && t64) orc_intersect_f64(&s, ro, rd, tNear, tFar, n, prim64, t64, threads);
 }
 
 typedef struct

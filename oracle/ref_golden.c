@@ -67,6 +67,9 @@ static const float4 kGiAxii[kGiDirections] =
 #include <stdlib.h>
 #include <string.h>
 
+/* the table BrdfLut_Sample reads (extern in math/lighting.h:45): data of the GGXEnergyCompensation record, see main() */
+BrdfLut g_BrdfLut;
+
 
 typedef union { float f; u32 u; i32 i; } word;
 
@@ -429,6 +432,24 @@ int main(int argc, char** argv)
         PUT4(plane.value); putf(a.x); putf(a.y); putf(b.x); putf(b.y); putf(c.x); putf(c.y); putf(TriArea3D(A, B, C));
     }
     end("lm_chartnode", N, 10, 11);
+
+    /* appended last so that the records above keep their inputs (one shared pseudo-random stream) */
+    /* BrdfLut_Sample / GGXEnergyCompensation (math/lighting.h:52-55,294-303) read the global table g_BrdfLut, which
+     * math/lighting.c defines and bakes from a clock-seeded stream.  lighting.c is not linked: the table is INPUT DATA of
+     * this record (a random 4x4 float2 table per case, stored with the case) and the global is defined below as such. */
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        static float2 tex[16];
+        for (int k = 0; k < 16; ++k) { tex[k].x = rnds(0.0f, 1.0f); tex[k].y = (i & 7) == 7 ? 0.0f : rnds(0.02f, 1.0f); putf(tex[k].x); putf(tex[k].y); }
+        g_BrdfLut.size = i2_s(4); g_BrdfLut.texels = tex;
+        float4 f0 = f4_v(rnd(), rnd(), rnd(), 0.0f); float NoV = rnds(-0.1f, 1.1f), alpha = rnds(0.0f, 1.05f);
+        PUT3(f0); putf(NoV); putf(alpha);
+        float2 a = BrdfLut_Sample(g_BrdfLut, NoV, alpha);
+        float4 e = GGXEnergyCompensation(f0, NoV, alpha);
+        putf(a.x); putf(a.y); PUT3(e);
+    }
+    end("GGXEnergyCompensation", N, 37, 5);
 
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);

@@ -220,7 +220,11 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
-    def add(self, mesh, t, q, s, mat):
+    def add(self, mesh, t, q, s, mat, uv_scale=None, uv_offset=None):
+        if uv_scale is not None or uv_offset is not None:
+            # a mesh of its own with uvs' = uvs * scale + offset (float32): texture coordinates outside [0, 1] and negative
+            sc_ = np.asarray(uv_scale if uv_scale is not None else (1.0, 1.0), F); of_ = np.asarray(uv_offset if uv_offset is not None else (0.0, 0.0), F)
+            mesh = (mesh[0].copy(), mesh[1].copy(), ((mesh[2] * sc_[None, :]).astype(F) + of_[None, :]).astype(F))
         P, N, U = flatten_entity(t, q, s, mesh)
         self.entities.append((mesh, np.asarray(t, F), np.asarray(q, F), np.asarray(s, F), mat))
         self.pos.append(P); self.nor.append(N); self.uv.append(U)
@@ -497,6 +501,85 @@ def cornell_box(prims="boxes", seed=1, sky_size=0, media=None, emissive_attempts
     return b.build()
 
 
+def pack_xy16(x, y):
+    """short2 texels of a tangent-space normal map (Xy16ToNormalTs, math/color.h:241-249): x in the low half"""
+    x = np.asarray(x, np.int32) & 0xffff; y = np.asarray(y, np.int32) & 0xffff
+    return (x | (y << 16)).astype(np.uint32)
+
+
+def textured_cornell(seed=1, emissive_attempts=1000, sky_size=0):
+    """CmdCornellBox's room (render_system.c:1110-1305) with REAL textures instead of GenFlatTexture's 1x1 ones, to drive
+    SampleAlbedo / SampleRome / SampleNormal (path_tracer.c:1328-1375), UvBilinearWrap_c32 / _xy16 (sampler.h:375-392)
+    and EmissionPdf (path_tracer.c:784-825) through every branch:
+      - non-square multi-texel rgba8 albedo (13x7) and ROME (10x10, 5x9) textures, xy16 normal maps (9x6, 4x11);
+      - uvs scaled and shifted outside [0, 1] and below 0 (the wrap's `u < 0 -> 1 - u` branch);
+      - a ROME whose alpha is non-zero on ONE texel of 100, on walls whose two triangles each cover half of the uv
+        square several times over: their EmissionPdf lands around the 1 % threshold (path_tracer.c:869);
+      - a ROME with an emissive stripe on a wall (part of each triangle emits), on top of the flat Cornell light."""
+    rng = np.random.default_rng(seed + 77)
+    b = SceneBuilder(seed=seed, sky_size=sky_size, emissive_attempts=emissive_attempts)
+    box, wallExtents = box_mesh(), F(5.0)
+    wallScale = _v3(F(2.0) * wallExtents, F(2.0) * wallExtents, kDeci)
+    fw, up_ = K_FORWARDS, K_UPS
+
+    def rgba8(r, g, b_, a):
+        return (np.asarray(r, np.uint32) | (np.asarray(g, np.uint32) << 8) | (np.asarray(b_, np.uint32) << 16) | (np.asarray(a, np.uint32) << 24)).astype(np.uint32)
+
+    # albedo 13 x 7: checker of two random palettes, alpha 255
+    ys, xs = np.meshgrid(np.arange(7), np.arange(13), indexing="ij")
+    chk = ((xs + ys) & 1).astype(bool)
+    alb = rgba8(np.where(chk, rng.integers(150, 256, (7, 13)), rng.integers(20, 120, (7, 13))),
+                rng.integers(60, 256, (7, 13)), np.where(chk, rng.integers(20, 90, (7, 13)), rng.integers(120, 256, (7, 13))), 255)
+    albTex = b.add_texture(13, 7, api.TEX_RGBA8, alb)
+    # ROME 10 x 10: roughness / occlusion / metallic vary, alpha non-zero on one texel of 100
+    a1 = np.zeros((10, 10), np.uint32); a1[6, 3] = 200
+    rome1 = rgba8(rng.integers(30, 256, (10, 10)), rng.integers(180, 256, (10, 10)), rng.integers(0, 2, (10, 10)) * 255, a1)
+    romeSpot = b.add_texture(10, 10, api.TEX_RGBA8, rome1)
+    # ROME 5 x 9: an emissive stripe (two texel rows of nine)
+    a2 = np.zeros((9, 5), np.uint32); a2[3:5, :] = rng.integers(90, 256, (2, 5))
+    rome2 = rgba8(rng.integers(100, 256, (9, 5)), 255, 0, a2)
+    romeStripe = b.add_texture(5, 9, api.TEX_RGBA8, rome2)
+    # ROME 3 x 2: smooth metal / rough plastic patches, no emission
+    rome3 = rgba8(np.array([[25, 230, 120], [200, 40, 90]]), 255, np.array([[255, 0, 255], [0, 255, 0]]), 0)
+    romeMetal = b.add_texture(3, 2, api.TEX_RGBA8, rome3)
+    # normal maps
+    n1 = pack_xy16(rng.integers(-9000, 9001, (6, 9)), rng.integers(-9000, 9001, (6, 9)))
+    nrm1 = b.add_texture(9, 6, api.TEX_XY16, n1)
+    n2 = pack_xy16(rng.integers(-20000, 20001, (11, 4)), rng.integers(-20000, 20001, (11, 4)))      # steep: FixShadingNormal's reflect branch
+    nrm2 = b.add_texture(4, 11, api.TEX_XY16, n2)
+
+    white, plastic, light = (0.9, 0.9, 0.9, 1.0), (0.9, 1.0, 0.0, 0.0), (0.9, 1.0, 0.0, 1.0)
+
+    def mat(albedo_tex=None, rome_tex=None, normal_tex=-1, rome=plastic, flags=0):
+        return b.material(white, rome, flags, albedo_tex=albedo_tex, rome_tex=rome_tex, normal_tex=normal_tex)
+
+    def wall(face_t, face_look, m, sc=None, of=None):
+        b.add(box, (fw[face_t] * wallExtents).astype(F), quat_lookat(fw[face_look], up_[face_look]), wallScale, m, uv_scale=sc, uv_offset=of)
+
+    wall(YM, YP, mat(albTex, None, nrm1), (3.7, -2.3), (-1.3, 0.6))                      # floor: albedo + normal map, negative uvs
+    wall(YP, YM, mat(None, romeSpot, -1, flags=api.MATFLAG_EMISSIVE), (2.0, 3.0), (0.25, -4.5))   # ceiling: ~1 % emissive texels
+    b.add(box, (fw[YP] * F(wallExtents - kDeci * F(2.0))).astype(F), quat_lookat(fw[YM], up_[YM]),
+          _v3(1.0, 1.0, kDeci), b.material((1.0, 1.0, 1.0, 1.0), light))                # Cornell_Light (flat)
+    wall(XM, XP, mat(albTex, romeStripe, -1, flags=api.MATFLAG_EMISSIVE), (1.0, 1.0), (0.0, 0.0))   # left: emissive stripe
+    wall(XP, XM, mat(albTex, romeMetal, nrm2), (-5.1, 1.9), (0.3, -0.2))                 # right: metal patches + steep normal map
+    wall(ZP, ZP, mat(None, romeSpot, nrm1, flags=api.MATFLAG_EMISSIVE), (0.37, 0.41), (7.2, 100.6))  # near: spot ROME seen through few texels
+    wall(ZM, ZM, mat(albTex, None, -1), (1.0, 1.0), (0.0, 0.0))                          # far: albedo only
+
+    def lerp(a, c, t):
+        return F(F(a) + F(F(c) - F(a)) * F(t))
+    boxScale = F(2.0); margin = F(boxScale * F(0.5))
+    lo = F(-wallExtents + margin); hi = F(wallExtents - margin)
+    b.add(box, _v3(lerp(lo, hi, 0.2), F(-wallExtents + boxScale), lerp(lo, hi, 0.2)),
+          quat_lookat(normalize3(_v3(0.2, 0.0, 1.0)), _v3(0, 1, 0)), _v3(boxScale, F(boxScale * F(2.0)), boxScale),
+          mat(albTex, romeMetal, nrm1), uv_scale=(2.5, 2.5), uv_offset=(-0.75, -0.1))
+    b.add(box, _v3(lerp(lo, hi, 0.8), F(-wallExtents + F(boxScale * F(0.5))), lerp(lo, hi, 0.8)),
+          quat_lookat(normalize3(_v3(-0.2, 0.0, 1.0)), _v3(0, 1, 0)), _v3(boxScale, boxScale, boxScale),
+          mat(albTex, romeStripe, nrm2, flags=api.MATFLAG_EMISSIVE), uv_scale=(1.0, -1.0), uv_offset=(0.0, 0.0))
+    sph = sphere_mesh(12)
+    b.add(sph, _v3(0.0, -3.5, 1.5), QUAT_ID, _v3(1.2, 1.2, 1.2), mat(albTex, romeMetal, nrm1), uv_scale=(4.0, 2.0), uv_offset=(-2.0, -1.0))
+    return b.build()
+
+
 def _random_quats(rng, n):
     q = rng.normal(size=(n, 4))
     return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
@@ -619,10 +702,11 @@ def surface_rays(scene, n, seed=0, offset=1e-4):
     return ro, rd
 
 
-def lightmap_pages_for(scene, lm_size, texels_per_meter, max_pages=None):
+def lightmap_pages_for(scene, lm_size, texels_per_meter, max_pages=None, tri_indices=None):
     """Synthetic bake inputs (the atlas packer is out of scope): every triangle gets
     its own chart rasterised at texels_per_meter into lm_size^2 pages in triangle order; covered texels get
     position / normal / sampleCounts = 1, like EmbedTaskFn's outputs (rendering/lightmap.c:1028-1030).
+    tri_indices: only these triangles, in this order (a bounded sample of a big scene).
     Returns a list of float32 pages in the reference layout [5][S*S]x4 | [S*S]x3 | [S*S]x3 | [S*S]."""
     S = lm_size
     L = S * S
@@ -637,7 +721,7 @@ def lightmap_pages_for(scene, lm_size, texels_per_meter, max_pages=None):
     cx = cy = rowh = 0
     P = scene.positions[:, :3].reshape(-1, 3, 3).astype(np.float64)
     Nn = scene.normals[:, :3].reshape(-1, 3, 3).astype(np.float64)
-    for t in range(P.shape[0]):
+    for t in (range(P.shape[0]) if tri_indices is None else tri_indices):
         a, b_, c = P[t]
         e1, e2 = b_ - a, c - a
         l1 = np.linalg.norm(e1)

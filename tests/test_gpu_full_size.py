@@ -117,3 +117,41 @@ def test_embed_full_size_pages_spot_checked_and_idempotent():
         assert np.abs(nrm - 1.0).max() < 1e-3
         covered += int(w[3][sel].sum())
     assert covered > 500
+
+
+def test_config4_lightmap_bake_of_the_1m_scene_at_density_16(big):
+    """BASELINE config 4 at its real scene size and density: LmPack_Bake (rendering/lightmap.c:1204-1223) of the 1M-triangle
+    scene at lm_density 16 into 1024^2 pages.  Bake inputs as SURVEY 8(d) prescribes (one chart per triangle, the packer
+    is outside rows a-e): the two inward-facing floor triangles (a page each: 1600 texels clamped to the page) and every
+    37th triangle of the objects (a third page of small charts), 1.47 M mapped texels.  EVERY probe and sample count of
+    EVERY page against the oracle's BakeFn, BIT-EXACT (portable-libm variant), over two progressive passes with
+    UpdateDists between them (the light histograms of pass 0 steer pass 1)."""
+    sc, g, o = big
+    S, tpm, spp = 1024, 16.0, 2
+    L = S * S
+    P = sc.positions[:84 * 3, :3].reshape(-1, 3, 3).astype(np.float64)          # the room: 7 boxes
+    n = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    inner = np.nonzero((0.5 * np.linalg.norm(n, axis=1) > 1000.0) & ((n * -P.mean(1)).sum(1) > 0))[0]
+    assert inner.size == 12
+    tris = list(inner[:2]) + list(range(84, sc.tri_count, 37))
+    pages = scenes.lightmap_pages_for(sc, S, tpm, max_pages=3, tri_indices=tris)
+    assert len(pages) == 3
+    mapped0 = [p[L * 26:].copy() for p in pages]
+    assert sum(int((m > 0).sum()) for m in mapped0) > 1_000_000
+    pg = [p.copy() for p in pages]
+    po = [p.copy() for p in pages]
+    o.threads = 16
+    for passIndex in range(2):
+        kw = dict(passIndex=passIndex, seed=7, maxBounces=8)
+        g.lightmap_bake(pg, S, tpm, 1.0, spp, **kw)
+        o.lightmap_bake(po, S, tpm, 1.0, spp, **kw)
+        for ip in range(len(pages)):
+            assert_bits_equal(pg[ip], po[ip], f"pass {passIndex} page {ip}")
+            want = np.where(mapped0[ip] > 0, mapped0[ip] + spp * (passIndex + 1), 0.0).astype(np.float32)
+            assert_bits_equal(pg[ip][L * 26:], want, f"pass {passIndex} page {ip} sampleCounts")
+            assert_bits_equal(pg[ip][L * 20:L * 26], pages[ip][L * 20:L * 26], f"page {ip} position/normal untouched")
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("live", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k)
+    lit = pg[2][:L * 4].reshape(L, 4)[mapped0[2] > 0]
+    assert np.isfinite(lit).all() and (lit[:, :3] > 0).mean() > 0.2

@@ -165,3 +165,20 @@ def copy_dof(d):
 def bits(a):
     """float32 array -> uint32 view for bit-exact comparisons"""
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def brute_positions(positions, ro, rd, tNear=None, tFar=None, want_f64=False, threads=16, portable=True):
+    """orc_brute_positions: the contract's fp32 closest hit over ALL triangles of a bare soup -> (prim, tuv);
+    with want_f64 also the fp64 ground truth -> (prim, tuv, prim64, t64)"""
+    lib = load_oracle(portable)
+    positions = api.f32(positions); ro, rd = api.f32(ro), api.f32(rd)
+    n = ro.shape[0]
+    tn = api.f32(tNear) if tNear is not None else np.zeros(n, np.float32)
+    tf = api.f32(tFar) if tFar is not None else np.full(n, api.RCP_EPSILON, np.float32)
+    prim = np.zeros(n, np.int32); tuv = np.zeros((n, 3), np.float32)
+    prim64 = np.zeros(n, np.int32) if want_f64 else None
+    t64 = np.zeros(n, np.float64) if want_f64 else None
+    lib.orc_brute_positions.restype = None
+    lib.orc_brute_positions(_p(positions), C.c_int32(positions.shape[0]), _p(ro), _p(rd), _p(tn), _p(tf), C.c_int32(n),
+                            _p(prim), _p(tuv), _p(prim64), _p(t64), C.c_int(threads))
+    return (prim, tuv, prim64, t64) if want_f64 else (prim, tuv)
