@@ -177,7 +177,8 @@ typedef struct PimDofInfo
     float   bladeRot;
     float   focalPlaneCurvature;
     float   autoFocusSpeed;
-    int32_t autoFocus;
+    uint8_t autoFocus;            /* bool at offset 24, as the reference's; the padding bytes are not read */
+    uint8_t _pad[3];
 } PimDofInfo;
 
 /* build-side extensions of one Pt_Trace call (D1, D2) */
@@ -357,6 +358,15 @@ typedef struct PimTraceStats
     float    totalMs;           /* device time of the whole call */
     uint64_t tailRays;          /* of the rays above: traced inside the tail kernel, which finishes the short queues of deep
                                    bounces in one launch (not by the batched traversal launches traceMs covers) */
+    /* device time of the other kernels of the call, from events attached to their dispatches (measurement: bench.py's
+     * per-kernel rooflines), and the units they processed */
+    float    shadeAMs;          /* k_shade_a, FAST + SLOW builds */
+    float    shadeBMs;          /* k_shade_b, FAST + SLOW builds */
+    float    tailMs;            /* k_tail */
+    int32_t  traceLaunches;     /* batched traversal launches traceMs covers */
+    uint64_t wavefrontPathBounces;  /* sum of the queue lengths at the start of every wavefront bounce: paths through shade_a / shade_b */
+    uint64_t tailPaths;         /* paths handed to the tail kernel */
+    uint64_t tailPathBounces;   /* bounces the tail kernel ran (one extension ray each) */
 } PimTraceStats;
 int pimgpu_trace_stats(const PimTrace* trace, PimTraceStats* out);
 

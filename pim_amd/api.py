@@ -63,7 +63,7 @@ class PimCamera(C.Structure):
 
 class PimDofInfo(C.Structure):
     _fields_ = [("aperture", C.c_float), ("focalLength", C.c_float), ("bladeCount", C.c_int32), ("bladeRot", C.c_float),
-                ("focalPlaneCurvature", C.c_float), ("autoFocusSpeed", C.c_float), ("autoFocus", C.c_int32)]
+                ("focalPlaneCurvature", C.c_float), ("autoFocusSpeed", C.c_float), ("autoFocus", C.c_uint8), ("_pad", C.c_uint8 * 3)]
 
 
 class PimTraceParams(C.Structure):
@@ -74,7 +74,8 @@ class PimTraceParams(C.Structure):
 class PimTraceStats(C.Structure):
     _fields_ = [("extensionRays", C.c_uint64), ("shadowRays", C.c_uint64), ("otherRays", C.c_uint64),
                 ("paths", C.c_uint64), ("bounces", C.c_int32), ("traceMs", C.c_float), ("totalMs", C.c_float),
-                ("tailRays", C.c_uint64)]
+                ("tailRays", C.c_uint64), ("shadeAMs", C.c_float), ("shadeBMs", C.c_float), ("tailMs", C.c_float),
+                ("traceLaunches", C.c_int32), ("wavefrontPathBounces", C.c_uint64), ("tailPaths", C.c_uint64), ("tailPathBounces", C.c_uint64)]
 
 
 class PimMesh(C.Structure):

@@ -27,6 +27,7 @@
 #include "pt_api.h"
 #include "pt_scene_fn.h"
 
+#include <hip/hip_ext.h>
 #include <cstring>
 #include <cstdlib>
 
@@ -800,6 +801,7 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
     block_add(&a.stats[1], shadow, sh);
     block_add(&a.stats[2], other, sh);
     block_add(&a.stats[5], ext + shadow, sh);        /* rays traced here, not by the batched traversal launches */
+    block_add(&a.stats[6], ext, sh);                 /* path-bounces run here */
     if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
 }
 
@@ -910,6 +912,7 @@ int stddev_scratch_setup(int device)
  */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 6));      /* tuning knobs, not API */
+static const int kTailMaxPaths = std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 350000));
 static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /* 0: 8 or 16 with the build below */
 /* Two builds of k_tail: 208 VGPRs (2 waves per SIMD) and <= 128 VGPRs with spills (4 per SIMD).  A tree that lives in L2
  * leaves little latency to hide and the spills cost more than the extra waves give (Cornell 2.22 against 2.29 ms); a
@@ -921,8 +924,11 @@ static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
     if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
     if (g.historyN != n || g.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
+    /* ... and in absolute terms no more than about what the machine holds at k_tail's occupancy: beyond that the tail is
+     * no longer latency-bound and its one-lane-per-path rays cost several times the batched ones (4K: 16.6 -> ms with n / 6) */
+    const int64_t threshold = std::min<int64_t>((int64_t)n / kTailFraction, kTailMaxPaths);
     for (int32_t b = 1; b < g.historyBounces && b < bounceLimit; ++b)
-        if ((int64_t)g.history[b] * kTailFraction < n) return b;
+        if ((int64_t)g.history[b] < threshold) return b;
     return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;
 }
 
@@ -977,7 +983,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     hipStream_t st = g.stream;
     const int32_t bounceLimit = (maxBounces > 0 && maxBounces < 666) ? maxBounces : 666;
     const int32_t tailBounce = tail_policy(g, n, bounceLimit);
-    g.first = first; g.n = n; g.wavefrontBounces = 0; g.events.clear(); g.eventsUsed = 0;
+    g.first = first; g.n = n; g.wavefrontBounces = 0; g.tailBounce = -1; g.events.clear(); g.eventsUsed = 0;
     { int rcT = g.trace->ensure(); if (rcT) return rcT; }      /* the spill area behind the kernels' traversal stacks: gridBlocks * 256 lanes */
     int32_t init[64] = {}; init[0] = n;
     PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
@@ -985,6 +991,10 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    /* events attached to the dispatches themselves (no barrier packets, trace.hip): cls 0 traversal, 1 shade_a, 2 shade_b, 3 tail */
+    auto timed = [&](int cls) { t0 = t1 = nullptr; if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ cls, t0, t1 }); else t0 = t1 = nullptr; } };
+#define PT_LAUNCH(kernel, grid, block, ...) do { if (t0 && t1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, t0, t1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, __VA_ARGS__); } while (0)
     int rc = PIMGPU_OK;
     int halves = 0;
     bool staggered = staggerAfter < 0;
@@ -1012,27 +1022,28 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
             const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 8);
             const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * wavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
             const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
-            if (dense) k_tail<4><<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
-            else k_tail<1><<<tailBlocks, kTailThreads, 0, st>>>(scene->d, a);
+            timed(3);
+            if (dense) PT_LAUNCH(k_tail<4>, tailBlocks, kTailThreads, scene->d, a);
+            else PT_LAUNCH(k_tail<1>, tailBlocks, kTailThreads, scene->d, a);
+            g.tailBounce = b;
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
         }
         ++g.wavefrontBounces;
-        t0 = t1 = nullptr;
-        if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ t0, t1 }); else t0 = t1 = nullptr; }
+        timed(0);
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st, t0, t1))) break;
-        k_shade_a<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
-        k_shade_a<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
+        timed(1); PT_LAUNCH(k_shade_a<false>, blocks, kShadeThreads, scene->d, a);
+        timed(1); PT_LAUNCH(k_shade_a<true>, slowBlocks, kShadeThreads, scene->d, a);
         half_done();
-        t0 = t1 = nullptr;
-        if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ t0, t1 }); else t0 = t1 = nullptr; }
+        timed(0);
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st, t0, t1))) break;
-        k_shade_b<false><<<blocks, kShadeThreads, 0, st>>>(scene->d, a);
-        k_shade_b<true><<<slowBlocks, kShadeThreads, 0, st>>>(scene->d, a);
+        timed(2); PT_LAUNCH(k_shade_b<false>, blocks, kShadeThreads, scene->d, a);
+        timed(2); PT_LAUNCH(k_shade_b<true>, slowBlocks, kShadeThreads, scene->d, a);
         half_done();
         if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
     }
     if (!staggered) hipEventRecord(g.stagger, st);
+#undef PT_LAUNCH
     return rc;
 }
 
@@ -1051,8 +1062,9 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     PT_HIP(hipMemcpyAsync(&traceStatus, g.trace->status, sizeof(traceStatus), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
     if (traceStatus & 1u) { PT_HIP(hipMemsetAsync(g.trace->status, 0, 4, st)); hs[4] |= 1ull; }
-    float traceMs = 0.0f;
-    for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.first, e.second); traceMs += ms; }
+    float clsMs[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; int32_t traceLaunches = 0;
+    for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.t0, e.t1); clsMs[e.cls] += ms; if (e.cls == 0) ++traceLaunches; }
+    const float traceMs = clsMs[0];
     g.events.clear();
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow (tree deeper than %d entries)", PT_STACK_MAX); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
@@ -1063,9 +1075,12 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     if (statsOut)
     {
         statsOut->extensionRays += hs[0]; statsOut->shadowRays += hs[1]; statsOut->otherRays += hs[2];
-        statsOut->tailRays += hs[5];
+        statsOut->tailRays += hs[5]; statsOut->tailPathBounces += hs[6];
         statsOut->bounces += g.wavefrontBounces;
         statsOut->paths += (uint64_t)g.n;
+        statsOut->shadeAMs += clsMs[1]; statsOut->shadeBMs += clsMs[2]; statsOut->tailMs += clsMs[3]; statsOut->traceLaunches += traceLaunches;
+        for (int32_t b = 0; b < g.wavefrontBounces && b < PT_COUNTS_MAX; ++b) statsOut->wavefrontPathBounces += (uint64_t)counts[PT_COUNTS_BASE + b];
+        if (g.tailBounce >= 0) statsOut->tailPaths += (uint64_t)counts[g.tailBounce & 1];
     }
     if (traceMsOut) *traceMsOut += traceMs;
     return PIMGPU_OK;

@@ -88,8 +88,9 @@ struct PathGroup
     /* queue length at the start of each wavefront bounce of the previous integrate call (host copy): the tail policy */
     int32_t history[64] = {}; int32_t historyBounces = 0; int64_t historyN = -1;
     /* the call in flight */
-    int32_t first = 0, n = 0, wavefrontBounces = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    int32_t first = 0, n = 0, wavefrontBounces = 0, tailBounce = -1;     /* tailBounce: bounce at which k_tail took over, -1 = never */
+    struct Timed { int cls; hipEvent_t t0, t1; };             /* cls: 0 traversal, 1 shade_a, 2 shade_b, 3 tail */
+    std::vector<Timed> events;
     std::vector<hipEvent_t> eventPool; size_t eventsUsed = 0;   /* timing events are made once and reused: creating and
                                                                     destroying 14 per frame was host time with the GPU idle */
     hipEvent_t take_event();

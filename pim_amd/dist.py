@@ -3,7 +3,7 @@ with no data-path collective except ONE reduce of the accumulated images at read
 
   image path   : samples sharded by index -- rank r of N renders samples r, r+N, r+2N, ...; each rank keeps its
                  own running-mean image; the mean over ranks (equal sample counts) is one SUM reduce / N
-  lightmap path: texel range sharded in contiguous tiles; disjoint writes, no reduction (gather only)
+  lightmap path: 64x64-texel tiles round-robin over the ranks (or contiguous ranges); disjoint writes, no reduction (gather only)
 
 torch.distributed is plumbing here (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 """
@@ -12,6 +12,27 @@ torch.distributed is plumbing here (backend "nccl" = RCCL over xGMI on the GPU b
 def sample_indices(rank, world, steps):
     """global sample indices rank `rank` renders in `steps` steps (disjoint across ranks, union = 0..steps*world-1)"""
     return [i * world + rank for i in range(steps)]
+
+
+def sample_range(rank, world, total):
+    """strong scaling (BASELINE config 3: "64 spp sharded"): contiguous [begin, end) of `total` samples for this rank,
+    sizes differing by at most one, union = 0..total-1"""
+    base, extra = divmod(total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def tile_owner(tile_index, world):
+    """lightmap bake (BASELINE config 4): 64x64-texel tiles round-robin over the ranks, so that the unmapped
+    texels, which cluster in the late pages, spread evenly"""
+    return tile_index % world
+
+
+def tiles_of(rank, world, lm_count, lm_size, tile=64):
+    """tile indices (page * tilesPerPage + ty * tilesPerRow + tx) rank `rank` bakes"""
+    per_row = (lm_size + tile - 1) // tile
+    total = lm_count * per_row * per_row
+    return list(range(rank, total, world))
 
 
 def texel_range(rank, world, total, tile=64 * 64):
@@ -23,11 +44,15 @@ def texel_range(rank, world, total, tile=64 * 64):
     return begin, end
 
 
-def reduce_mean_image(tensor, world, dist, dst=0):
-    """the path's one exchange step: tensor holds this rank's mean image (equal sample counts on every rank);
-    after the call rank `dst` holds the mean over all ranks' samples"""
+def reduce_mean_image(tensor, world, dist, dst=0, weight=None, total=None):
+    """the path's one exchange step: tensor holds this rank's mean image; after the call rank `dst` holds the mean over
+    all ranks' samples.  Equal sample counts (weight None, or weight * world == total): SUM reduce, then / world.
+    Unequal counts (strong scaling with a remainder): every rank scales by weight / total first."""
     if world > 1:
+        equal = weight is None or total is None or weight * world == total
+        if not equal:
+            tensor.mul_(float(weight) / float(total))
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
-        if dist.get_rank() == dst:
+        if equal and dist.get_rank() == dst:
             tensor.mul_(1.0 / world)
     return tensor

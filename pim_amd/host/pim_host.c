@@ -1,15 +1,48 @@
 /*
- * pim_host.c -- Pim's path-tracer entry points (rendering/path_tracer.h:67-103, lightmap.h:69) as thin C
- * wrappers over libpimgpu.so.  No arithmetic of the path happens here: every function marshals its
- * arguments, makes one C-ABI call and hands the result back in the reference's host-side shape.
+ * pim_host.c -- Pim's path-tracer entry points (rendering/path_tracer.h:67-103, lightmap.h:56-69, cubemap.h:209,
+ * ambcube.h:69) with their own signatures, as thin C wrappers over libpimgpu.so.  No arithmetic of the path happens
+ * here: every function marshals its arguments, makes C-ABI calls and hands the result back in the reference's host-side
+ * shape.  State the reference keeps in globals / per-thread contexts (the scene source, the Prng streams, the lightmap
+ * pack, the frame arena of Pt_RayGen) is kept here in file-scope variables, as path_tracer.c keeps ms_contexts and
+ * lightmap.c keeps ms_pack.
  */
 #include "pim_host.h"
 
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+_Static_assert(sizeof(float4) == 16 && _Alignof(float4) == 16, "float4 (math/types.h:66-73)");
+_Static_assert(sizeof(PtRayHit) == 48 && sizeof(PimRayHit) == 48, "PtRayHit (path_tracer.h:24-31)");
+_Static_assert(sizeof(PtDofInfo) == 28 && sizeof(PimDofInfo) == 28 && offsetof(PtDofInfo, autoFocus) == 24 && offsetof(PimDofInfo, autoFocus) == 24, "PtDofInfo (path_tracer.h:33-42)");
+_Static_assert(sizeof(PtResult) == 36 && sizeof(PimResult) == 36, "PtResult (path_tracer.h:54-59)");
+_Static_assert(sizeof(Camera) == 48 && sizeof(PimCamera) == 48, "Camera (rendering/camera.h:8-15)");
+_Static_assert(sizeof(PtTrace) == 48, "PtTrace (path_tracer.h:44-52)");
+_Static_assert(sizeof(vkrTextureId) == 4, "vkrTextureId (vkr.h:125-131)");
+
+struct PtScene_s
+{
+    PimScene* gpu;
+    uint64_t modtime;         /* PtScene.modtime, path_tracer.c:164 */
+    bool fromProvider;
+};
+
 static char ms_error[512];
+static bool ms_ok;
+static PtSysConfig ms_config = { 0x9E3779B9u, 0, 1.0f / 60.0f, 1, -1 };
+static PtSysCounters ms_counters;
+static PtSceneProviderFn ms_provider;
+static void* ms_providerUser;
+static LmPack ms_pack;                       /* lightmap.c:79 */
+
+/* PtTrace is the caller's struct and has no room for the device handle: a side table keyed by the color pointer */
+#define kMaxTraces 64
+static struct { float3* key; PimTrace* gpu; } ms_traces[kMaxTraces];
+/* Pt_RayGen's results live in the reference's Temp_ frame arena (path_tracer.c:2630-2631): freed by PtSys_Update */
+#define kMaxFrameAllocs 256
+static void* ms_frameAllocs[kMaxFrameAllocs];
+static int ms_frameAllocCount;
 
 static bool ok(int rc, const char* what)
 {
@@ -19,26 +52,115 @@ static bool ok(int rc, const char* what)
     return false;
 }
 
-const char* PtSys_LastError(void) { return ms_error; }
-
-bool PtSys_Init(void)
+static void fail(const char* what)
 {
-    const char* dev = getenv("PIM_GPU_DEVICE");
-    return ok(pimgpu_init(dev ? atoi(dev) : 0), "PtSys_Init");
+    snprintf(ms_error, sizeof(ms_error), "%s", what);
+    fprintf(stderr, "[pt] %s\n", ms_error);
 }
 
-void PtSys_Shutdown(void) { pimgpu_shutdown(); }
+const char* PtSys_LastError(void) { return ms_error; }
+bool PtSys_Ok(void) { return ms_ok; }
 
-PtScene* PtScene_New(const PimSceneDesc* snapshot)
+void PtSys_Configure(const PtSysConfig* config)
 {
-    PtScene* scene = NULL;
-    if (!ok(pimgpu_scene_create(snapshot, &scene), "PtScene_New")) return NULL;
+    if (config) ms_config = *config;
+    if (!(ms_config.frameDt > 0.0f)) ms_config.frameDt = 1.0f / 60.0f;
+    memset(&ms_counters, 0, sizeof(ms_counters));
+}
+
+void PtSys_GetCounters(PtSysCounters* out) { if (out) *out = ms_counters; }
+void PtSys_SetSceneProvider(PtSceneProviderFn fn, void* user) { ms_provider = fn; ms_providerUser = user; }
+
+void PtSys_Init(void)
+{
+    int device = ms_config.device;
+    if (device < 0) { const char* dev = getenv("PIM_GPU_DEVICE"); device = dev ? atoi(dev) : 0; }
+    ms_ok = ok(pimgpu_init(device), "PtSys_Init");
+}
+
+void PtSys_Update(void)
+{
+    for (int i = 0; i < ms_frameAllocCount; ++i) free(ms_frameAllocs[i]);
+    ms_frameAllocCount = 0;
+}
+
+void PtSys_Shutdown(void)
+{
+    PtSys_Update();
+    pimgpu_shutdown();
+    ms_ok = false;
+}
+
+/* ---- scene ---- */
+
+PimScene* PtScene_Gpu(const PtScene* scene) { return scene ? scene->gpu : NULL; }
+
+PtScene* PtScene_NewFromSnapshot(const PimSceneDesc* snapshot)
+{
+    PimScene* gpu = NULL;
+    if (!ok(pimgpu_scene_create(snapshot, &gpu), "PtScene_New")) return NULL;
+    PtScene* scene = calloc(1, sizeof(*scene));              /* Perm_Calloc, path_tracer.c:1087 */
+    if (!scene) { pimgpu_scene_destroy(gpu); return NULL; }
+    scene->gpu = gpu;
     return scene;
+}
+
+PtScene* PtScene_New(void)
+{
+    if (!ms_provider) { fail("PtScene_New: no scene provider (PtSys_SetSceneProvider)"); return NULL; }
+    PimSceneDesc desc; memset(&desc, 0, sizeof(desc));
+    uint64_t modtime = 0;
+    if (!ms_provider(&desc, &modtime, 0, ms_providerUser)) { fail("PtScene_New: the scene provider failed"); return NULL; }
+    PtScene* scene = PtScene_NewFromSnapshot(&desc);
+    if (scene) { scene->modtime = modtime; scene->fromProvider = true; }
+    return scene;
+}
+
+/* the first half of PtScene_Update (path_tracer.c:1028-1032): Entities_Get()->modtime != scene->modtime -> PtScene_Clear +
+ * PtScene_Init, in place.  Returns true when the scene was rebuilt. */
+static bool scene_refresh(PtScene* scene)
+{
+    if (!scene->fromProvider || !ms_provider) return false;
+    uint64_t modtime = scene->modtime;
+    PimSceneDesc desc; memset(&desc, 0, sizeof(desc));
+    if (!ms_provider(&desc, &modtime, 1, ms_providerUser) || modtime == scene->modtime) return false;
+    memset(&desc, 0, sizeof(desc));
+    if (!ms_provider(&desc, &modtime, 0, ms_providerUser)) { fail("PtScene_Update: the scene provider failed"); return false; }
+    PimScene* gpu = NULL;
+    if (!ok(pimgpu_scene_create(&desc, &gpu), "PtScene_Update")) return false;
+    pimgpu_scene_destroy(scene->gpu);
+    scene->gpu = gpu; scene->modtime = modtime;
+    return true;
+}
+
+void PtScene_Update(PtScene* scene)
+{
+    if (!scene) return;
+    scene_refresh(scene);
+    ok(pimgpu_scene_update_dists(scene->gpu), "PtScene_Update");      /* UpdateDists, :1034 */
+}
+
+void PtScene_Del(PtScene* scene)
+{
+    if (!scene) return;
+    pimgpu_scene_destroy(scene->gpu);
+    free(scene);
+}
+
+void PtScene_Gui(PtScene* scene)
+{
+    if (!scene) return;
+    PimSceneInfo info;
+    if (!ok(pimgpu_scene_info(scene->gpu, &info), "PtScene_Gui")) return;
+    /* path_tracer.c:1104-1115 */
+    printf("Vertex Count: %d\nMaterial Count: %d\nEmissive Count: %d\n", info.vertCount, info.matCount, info.emissiveCount);
+    printf("Light Grid: %d x %d x %d, %d of %d cells lit; BVH: %d nodes, %d levels, built in %.3f ms\n",
+        info.gridSize[0], info.gridSize[1], info.gridSize[2], info.activeCells, info.gridLen, info.bvhNodeCount, info.bvhMaxDepth, info.bvhBuildMs);
 }
 
 PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneDesc* rest)
 {
-    if (!rest) { snprintf(ms_error, sizeof(ms_error), "PtScene_NewFromDrawables: NULL snapshot"); return NULL; }
+    if (!rest) { fail("PtScene_NewFromDrawables: NULL snapshot"); return NULL; }
     int32_t vertCount = 0, matCount = 0;
     if (!ok(pimgpu_flatten_counts(drawables, &vertCount, &matCount), "FlattenDrawables")) return NULL;
     /* Perm_Calloc in the reference (path_tracer.c:715-721) */
@@ -54,31 +176,39 @@ PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneD
         PimSceneDesc desc = *rest;
         desc.vertCount = vertCount; desc.matCount = matCount;
         desc.positions = positions; desc.normals = normals; desc.uvs = uvs; desc.matIds = matIds; desc.materials = materials;
-        scene = PtScene_New(&desc);
+        scene = PtScene_NewFromSnapshot(&desc);
     }
     free(positions); free(normals); free(uvs); free(matIds); free(materials);      /* the scene keeps its own copies in HBM */
     return scene;
 }
 
-BrdfLut BrdfLut_New(int2 size, i32 numSamples, uint32_t seed)
+/* ---- BRDF table ---- */
+
+BrdfLut BrdfLut_New(int2 size, i32 numSamples)
 {
-    BrdfLut lut = { size, NULL };
+    BrdfLut lut; lut.size = size; lut.texels = NULL;
     if (size.x <= 0 || size.y <= 0) { lut.size.x = lut.size.y = 0; return lut; }
     lut.texels = calloc((size_t)size.x * (size_t)size.y, sizeof(float2));           /* Tex_Calloc, lighting.c:92 */
-    if (lut.texels) BrdfLut_Update(&lut, 0, numSamples, seed);
+    if (lut.texels) BrdfLut_Update(&lut, 0, numSamples);
     return lut;
 }
 
-void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples, uint32_t seed)
+void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples)
 {
     if (lut && lut->texels && (newSamples > prevSamples))                           /* lighting.c:110 */
-        ok(pimgpu_brdf_lut_bake(&lut->texels[0].x, lut->size.x, lut->size.y, prevSamples, newSamples, seed), "BrdfLut_Update");
+        ok(pimgpu_brdf_lut_bake(&lut->texels[0].x, lut->size.x, lut->size.y, prevSamples, newSamples, ms_config.seed), "BrdfLut_Update");
 }
 
 void BrdfLut_Del(BrdfLut* lut) { if (lut) { free(lut->texels); memset(lut, 0, sizeof(*lut)); } }
 
-void PtScene_Update(PtScene* scene) { if (scene) ok(pimgpu_scene_update_dists(scene), "PtScene_Update"); }
-void PtScene_Del(PtScene* scene) { if (scene) pimgpu_scene_destroy(scene); }
+/* ---- images ---- */
+
+static int trace_find(const float3* key)
+{
+    if (!key) return -1;
+    for (int i = 0; i < kMaxTraces; ++i) if (ms_traces[i].key == key) return i;
+    return -1;
+}
 
 void PtTrace_New(PtTrace* trace, int2 imageSize)
 {
@@ -86,21 +216,34 @@ void PtTrace_New(PtTrace* trace, int2 imageSize)
     memset(trace, 0, sizeof(*trace));
     const size_t texelCount = (size_t)imageSize.x * (size_t)imageSize.y;
     if (!texelCount) return;
-    if (!ok(pimgpu_trace_create(imageSize.x, imageSize.y, &trace->gpu), "PtTrace_New")) return;
+    int slot = -1;
+    for (int i = 0; i < kMaxTraces && slot < 0; ++i) if (!ms_traces[i].key) slot = i;
+    if (slot < 0) { fail("PtTrace_New: too many live PtTrace objects"); return; }
+    PimTrace* gpu = NULL;
+    if (!ok(pimgpu_trace_create(imageSize.x, imageSize.y, &gpu), "PtTrace_New")) return;
     trace->imageSize = imageSize;
-    /* Tex_Calloc in the reference; page-locked here: Pt_Trace copies the three images back on every call */
+    /* Tex_Calloc in the reference; page-locked here: Pt_Trace copies the images back on every call */
     trace->color = pimgpu_host_alloc(texelCount * sizeof(float3));
     trace->albedo = pimgpu_host_alloc(texelCount * sizeof(float3));
     trace->normal = pimgpu_host_alloc(texelCount * sizeof(float3));
     trace->denoised = pimgpu_host_alloc(texelCount * sizeof(float3));
     trace->sampleWeight = 1.0f;
-    trace->frameDt = 1.0f / 60.0f;
+    if (!trace->color || !trace->albedo || !trace->normal || !trace->denoised)
+    {
+        pimgpu_trace_destroy(gpu);
+        pimgpu_host_free(trace->color); pimgpu_host_free(trace->albedo); pimgpu_host_free(trace->normal); pimgpu_host_free(trace->denoised);
+        memset(trace, 0, sizeof(*trace));
+        fail("PtTrace_New: out of page-locked host memory");
+        return;
+    }
+    ms_traces[slot].key = trace->color; ms_traces[slot].gpu = gpu;
 }
 
 void PtTrace_Del(PtTrace* trace)
 {
     if (!trace) return;
-    pimgpu_trace_destroy(trace->gpu);
+    const int slot = trace_find(trace->color);
+    if (slot >= 0) { pimgpu_trace_destroy(ms_traces[slot].gpu); ms_traces[slot].key = NULL; ms_traces[slot].gpu = NULL; }
     pimgpu_host_free(trace->color); pimgpu_host_free(trace->albedo); pimgpu_host_free(trace->normal); pimgpu_host_free(trace->denoised);
     memset(trace, 0, sizeof(*trace));
 }
@@ -113,77 +256,118 @@ void DofInfo_New(PtDofInfo* dof)
     dof->bladeCount = 5;
     dof->bladeRot = 3.1415926535897932384626433832795f / 10.0f;
     dof->focalPlaneCurvature = 0.05f;
-    dof->autoFocus = 1;
+    dof->autoFocus = true;
     dof->autoFocusSpeed = 3.0f;
 }
 
-PtRayHit Pt_Intersect(PtScene* scene, float4 ro, float4 rd, float tNear, float tFar)
+void DofInfo_Gui(PtDofInfo* dof)
+{
+    if (!dof) return;
+    /* path_tracer.c:1155-1178: the values its sliders show */
+    printf("Aperture: %g mm\nFocal Length: %g m\nBlade Count: %d\nBlade Rotation: %g\nFocal Plane Curvature: %g\nAutofocus: %s (speed %g)\n",
+        dof->aperture * 1e3f, dof->focalLength, dof->bladeCount, dof->bladeRot, dof->focalPlaneCurvature, dof->autoFocus ? "on" : "off", dof->autoFocusSpeed);
+}
+
+static PimDofInfo dof_to_gpu(const PtDofInfo* d)
+{
+    PimDofInfo g; memset(&g, 0, sizeof(g));
+    g.aperture = d->aperture; g.focalLength = d->focalLength; g.bladeCount = d->bladeCount; g.bladeRot = d->bladeRot;
+    g.focalPlaneCurvature = d->focalPlaneCurvature; g.autoFocusSpeed = d->autoFocusSpeed; g.autoFocus = d->autoFocus ? 1 : 0;
+    return g;
+}
+
+PtRayHit Pt_Intersect(const PtScene* scene, float4 ro, float4 rd, float tNear, float tFar)
 {
     PimRayHit h; memset(&h, 0, sizeof(h)); h.wuvt[3] = -1.0f; h.iVert = -1;
-    ok(pimgpu_intersect(scene, &ro.x, &rd.x, &tNear, &tFar, 1, &h), "Pt_Intersect");
+    if (scene) ok(pimgpu_intersect(scene->gpu, &ro.x, &rd.x, &tNear, &tFar, 1, &h), "Pt_Intersect");
     PtRayHit out;
     memcpy(&out.wuvt, h.wuvt, sizeof(float4)); memcpy(&out.normal, h.normal, sizeof(float4));
-    out.type = h.type; out.iVert = h.iVert; out.flags = h.flags;
+    out.type = (PtHitType)h.type; out.iVert = h.iVert; out.flags = h.flags;
     return out;
 }
 
-PtResult Pt_TraceRay(PtScene* scene, float4 ro, float4 rd, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+PtResult Pt_TraceRayEx(PtScene* scene, float4 ro, float4 rd, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
 {
     PimResult r; memset(&r, 0, sizeof(r));
-    ok(pimgpu_trace_rays(scene, &ro.x, &rd.x, 1, sampleIndex, seed, maxBounces, &r), "Pt_TraceRay");
+    if (scene) ok(pimgpu_trace_rays(scene->gpu, &ro.x, &rd.x, 1, sampleIndex, seed, maxBounces, &r), "Pt_TraceRay");
     PtResult out; memcpy(&out, &r, sizeof(out));
     return out;
 }
 
-void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* camera)
+PtResult Pt_TraceRay(PtScene* scene, float4 ro, float4 rd)
 {
-    if (!trace || !trace->gpu || !dof || !scene || !camera) return;
-    PimTraceParams p;
-    p.sampleWeight = trace->sampleWeight;
-    p.frameDt = trace->frameDt;
-    p.sampleIndex = trace->sampleIndex;
-    p.seed = trace->seed;
-    p.maxBounces = trace->maxBounces;
-    p.updateDists = 1;                                   /* PtScene_Update, path_tracer.c:2565 */
-    if (!ok(pimgpu_trace_image(scene, trace->gpu, camera, dof, &p), "Pt_Trace")) return;
-    trace->sampleIndex++;
-    /* the reference's callers read the host images right after Pt_Trace (render_system.c:306-352) */
-    ok(pimgpu_trace_download(trace->gpu, &trace->color->x, &trace->albedo->x, &trace->normal->x), "Pt_Trace");
+    return Pt_TraceRayEx(scene, ro, rd, ms_counters.traceRay++, ms_config.seed, ms_config.maxBounces);
 }
 
-PtResults Pt_RayGen(PtScene* scene, float4 origin, i32 count, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* camera)
+{
+    if (!trace || !dof || !scene || !camera) return;
+    const int slot = trace_find(trace->color);
+    if (slot < 0) { fail("Pt_Trace: this PtTrace was not made by PtTrace_New"); return; }
+    scene_refresh(scene);                                /* PtScene_Update, path_tracer.c:2565: rebuild on a new modtime ... */
+    PimTraceParams p;
+    p.sampleWeight = trace->sampleWeight;
+    p.frameDt = ms_config.frameDt;
+    p.sampleIndex = ms_counters.trace;
+    p.seed = ms_config.seed;
+    p.maxBounces = ms_config.maxBounces;
+    p.updateDists = 1;                                   /* ... and UpdateDists (:1034), enqueued with the frame */
+    PimDofInfo gdof = dof_to_gpu(dof);
+    PimCamera cam; memcpy(&cam, camera, sizeof(cam));
+    if (!ok(pimgpu_trace_image(scene->gpu, ms_traces[slot].gpu, &cam, &gdof, &p), "Pt_Trace")) return;
+    dof->focalLength = gdof.focalLength;                 /* DofUpdate, path_tracer.c:2485-2503 */
+    ms_counters.trace++;
+    /* the reference's callers read the host images right after Pt_Trace (render_system.c:306-352) */
+    const bool aovs = ms_config.downloadAovs != 0;
+    ok(pimgpu_trace_download(ms_traces[slot].gpu, &trace->color->x, aovs ? &trace->albedo->x : NULL, aovs ? &trace->normal->x : NULL), "Pt_Trace");
+}
+
+void PtTrace_DownloadAovs(PtTrace* trace)
+{
+    if (!trace) return;
+    const int slot = trace_find(trace->color);
+    if (slot >= 0) ok(pimgpu_trace_download(ms_traces[slot].gpu, NULL, &trace->albedo->x, &trace->normal->x), "PtTrace_DownloadAovs");
+}
+
+PtResults Pt_RayGen(PtScene* scene, float4 origin, i32 count)
 {
     PtResults r = { NULL, NULL };
-    if (count <= 0) return r;
-    r.colors = calloc((size_t)count, sizeof(float4));
+    if (!scene || count <= 0) return r;
+    if (ms_frameAllocCount + 2 > kMaxFrameAllocs) PtSys_Update();       /* a caller that never ends its frames */
+    r.colors = calloc((size_t)count, sizeof(float4));                   /* Temp_Alloc, path_tracer.c:2630-2631 */
     r.directions = calloc((size_t)count, sizeof(float4));
-    if (!ok(pimgpu_raygen(scene, &origin.x, count, sampleIndex, seed, maxBounces, &r.colors->x, &r.directions->x), "Pt_RayGen"))
-        PtResults_Del(&r);
+    if (!r.colors || !r.directions ||
+        !ok(pimgpu_raygen(scene->gpu, &origin.x, count, ms_counters.rayGen, ms_config.seed, ms_config.maxBounces, &r.colors->x, &r.directions->x), "Pt_RayGen"))
+    {
+        free(r.colors); free(r.directions);
+        r.colors = NULL; r.directions = NULL;
+        return r;
+    }
+    ms_counters.rayGen++;
+    ms_frameAllocs[ms_frameAllocCount++] = r.colors;
+    ms_frameAllocs[ms_frameAllocCount++] = r.directions;
     return r;
 }
 
-void PtResults_Del(PtResults* results)
-{
-    if (!results) return;
-    free(results->colors); free(results->directions);
-    results->colors = NULL; results->directions = NULL;
-}
-
-void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight)
 {
     if (!cm || !scene || cm->size <= 0) return;                      /* cubemap.c:168-173 */
     float* faces[6];
     for (int f = 0; f < 6; ++f) faces[f] = &cm->color[f]->x;
-    ok(pimgpu_cubemap_bake(scene, faces, cm->size, &origin.x, weight, sampleIndex, seed, maxBounces), "Cubemap_Bake");
+    if (ok(pimgpu_cubemap_bake(scene->gpu, faces, cm->size, &origin.x, weight, ms_counters.cubemap, ms_config.seed, ms_config.maxBounces), "Cubemap_Bake"))
+        ms_counters.cubemap++;
 }
 
-i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount, uint32_t sampleIndex, uint32_t seed, i32 maxBounces)
+i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount)
 {
     i32 count = prevSampleCount;
     if (!scene || !pCube) return count;
-    ok(pimgpu_ambcube_bake(scene, &pCube->Values[0].x, &origin.x, samples, prevSampleCount, sampleIndex, seed, maxBounces, &count), "AmbCube_Bake");
+    if (ok(pimgpu_ambcube_bake(scene->gpu, &pCube->Values[0].x, &origin.x, samples, prevSampleCount, ms_counters.rayGen, ms_config.seed, ms_config.maxBounces, &count), "AmbCube_Bake"))
+        ms_counters.rayGen++;                                        /* AmbCube_Bake is a Pt_RayGen call (ambcube.c:17) */
     return count;
 }
+
+/* ---- lightmaps ---- */
 
 void Lightmap_New(Lightmap* lm, i32 size)
 {
@@ -195,7 +379,7 @@ void Lightmap_New(Lightmap* lm, i32 size)
      * page (113 MB at 1024^2) to the device and back on every call */
     float* allocation = pimgpu_host_alloc(texelcount * 27 * sizeof(float));
     if (!allocation) { lm->size = 0; return; }
-    for (i32 i = 0; i < 5; ++i) lm->probes[i] = (float4*)(allocation + texelcount * 4 * (size_t)i);
+    for (i32 i = 0; i < kGiDirections; ++i) lm->probes[i] = (float4*)(allocation + texelcount * 4 * (size_t)i);
     lm->position = (float3*)(allocation + texelcount * 20);
     lm->normal = (float3*)(allocation + texelcount * 23);
     lm->sampleCounts = allocation + texelcount * 26;
@@ -206,21 +390,36 @@ void Lightmap_Del(Lightmap* lm)
     if (lm) { pimgpu_host_free(lm->probes[0]); memset(lm, 0, sizeof(*lm)); }
 }
 
+LmPack* LmPack_Get(void) { return &ms_pack; }
+
+void LmPack_Del(LmPack* pack)
+{
+    if (!pack) return;
+    for (i32 i = 0; i < pack->lmCount; ++i) Lightmap_Del(pack->lightmaps + i);      /* lightmap.c:1104-1115 */
+    free(pack->lightmaps);
+    memset(pack, 0, sizeof(*pack));
+}
+
 void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, const i32* texIds, i32 lmCount)
 {
     if (!drawables || !lightmaps || lmCount <= 0) return;
     PimLightmapPage* pages = calloc((size_t)lmCount, sizeof(PimLightmapPage));
+    if (!pages) return;
     for (i32 i = 0; i < lmCount; ++i) pages[i].block = &lightmaps[i].probes[0]->x;
     ok(pimgpu_lightmap_embed(drawables, texIds, pages, lmCount, lightmaps[0].size), "LmPack_EmbedAttributes");
     free(pages);
 }
 
-void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces)
+void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp)
 {
-    if (!scene || !pack || pack->lmCount <= 0) return;
+    const LmPack* pack = LmPack_Get();                                   /* lightmap.c:1211 */
+    if (!scene || pack->lmCount <= 0 || !pack->lightmaps) return;
     PimLightmapPage* pages = calloc((size_t)pack->lmCount, sizeof(PimLightmapPage));
+    if (!pages) return;
     for (i32 i = 0; i < pack->lmCount; ++i) pages[i].block = &pack->lightmaps[i].probes[0]->x;   /* lightmap.c:95-110 */
-    ok(pimgpu_lightmap_bake(scene, pages, pack->lmCount, pack->lmSize, pack->texelsPerMeter, timeSlice, spp,
-        passIndex, seed, maxBounces, 0, -1), "LmPack_Bake");
+    scene_refresh(scene);                                                /* PtScene_Update, lightmap.c:1209; its UpdateDists runs inside the bake call */
+    if (ok(pimgpu_lightmap_bake(scene->gpu, pages, pack->lmCount, pack->lmSize, pack->texelsPerMeter, timeSlice, spp > 1 ? spp : 1,
+        ms_counters.lmBake, ms_config.seed, ms_config.maxBounces, 0, -1), "LmPack_Bake"))
+        ms_counters.lmBake++;
     free(pages);
 }

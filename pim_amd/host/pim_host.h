@@ -1,18 +1,24 @@
 /*
- * pim_host.h -- plain C host layer with the names, argument meaning and error behaviour of Pim's own
- * path-tracer API (rendering/path_tracer.h:67-103, rendering/lightmap.h:56-72), implemented over the
- * C-ABI of libpimgpu.so (include/pimgpu.h).  This is the "C host code calling HIP through a thin
- * C-ABI layer": a Pim build replaces rendering/path_tracer.c and the BakeFn part of
- * rendering/lightmap.c with this file's implementation (pim_host.c) and links libpimgpu.so.
+ * pim_host.h -- plain C host layer with the names, SIGNATURES, struct layouts and error behaviour of Pim's own
+ * path-tracer API (rendering/path_tracer.h:13-103, rendering/lightmap.h:27-72, rendering/cubemap.h:28-34,209-213,
+ * math/ambcube.h:69-74), implemented over the C-ABI of libpimgpu.so (include/pimgpu.h).  This is the "C host code
+ * calling HIP through a thin C-ABI layer": a Pim build drops rendering/path_tracer.c and the BakeFn part of
+ * rendering/lightmap.c, compiles pim_host.c instead and links libpimgpu.so; the callers in render_system.c, cubemap.c and
+ * ambcube.c compile unchanged against their own headers (tests/host/ref_caller.c is such a caller).
  *
- * Differences from the reference signatures, all forced by the device boundary:
- *   - PtScene_New takes the scene SNAPSHOT (PimSceneDesc) instead of pulling Entities_Get(),
- *     Texture_Get(), Cubemaps_Get(), g_BrdfLut and cv_pt_dist_meters from global singletons;
- *     INTEGRATION.md shows the few lines that fill the snapshot from those singletons;
- *   - the Prng streams are per pixel / ray / texel and take an explicit seed and sample index
- *     (SURVEY D1), carried in PtTrace / the extra arguments;
- *   - errors: NULL / false returns + a message (PtSys_LastError), like the reference's
- *     NULL scene + Con_Logf (path_tracer.c:389-396, 645-651, 1085-1089).
+ * PART 1 below is the reference's interface, prototype for prototype.  What the reference pulls from global singletons or
+ * keeps in per-thread state has no parameter there, so it has none here either; PART 2 (extensions, `PtSys_*Ex`, `*Ex`)
+ * is how the embedding code supplies it:
+ *   - the scene: PtScene_New(void) / PtScene_Update read Entities_Get(), Texture_Get(), Cubemaps_Get(), g_BrdfLut,
+ *     cv_pt_dist_meters (path_tracer.c:692-782,1011-1049).  Here they call the SNAPSHOT PROVIDER registered with
+ *     PtSys_SetSceneProvider, which fills a PimSceneDesc from those singletons (INTEGRATION.md shows it) and reports
+ *     Entities.modtime; a changed modtime rebuilds the scene in place, as PtScene_Update does (:1028-1032);
+ *   - the Prng streams: per host thread and clock-seeded in the reference (path_tracer.c:168-176,410-414); per work item here
+ *     (SURVEY D1), derived from the seed of PtSys_Configure and from call counters the library keeps, as the reference keeps
+ *     its streams: Pt_Trace call k renders sample index k, Pt_TraceRay call k is stream k, and so on;
+ *   - the bounce clamp and Time_Deltaf(): PtSys_Configure (0 = the reference's roulette-only termination; 1/60 s).
+ * Errors: the reference has no error codes (NULL scene, Con_Logf + ASSERT); here a failed call logs to stderr, leaves its
+ * outputs untouched / returns NULL, and PtSys_LastError() returns the message.
  */
 #ifndef PIM_HOST_H
 #define PIM_HOST_H
@@ -25,89 +31,121 @@
 extern "C" {
 #endif
 
-typedef struct { float x, y, z, w; } float4;
-typedef struct { float x, y, z; } float3;
-typedef struct { int32_t x, y; } int2;
+/* ---- the reference's plain types (math/types.h:52-73,152-157; same size and alignment) ---- */
 typedef int32_t i32;
+typedef uint32_t u32;
+typedef struct float2_s { _Alignas(8) float x; float y; } float2;
+typedef struct float3_s { float x, y, z; } float3;
+typedef struct float4_s { _Alignas(16) float x; float y, z, w; } float4;
+typedef struct int2_s { _Alignas(8) i32 x; i32 y; } int2;
+typedef struct quat_s { float4 v; } quat;
 
-typedef PimScene PtScene;                 /* opaque, path_tracer.h:13 */
-typedef PimDofInfo PtDofInfo;             /* path_tracer.h:33-42 */
-typedef PimCamera Camera;                 /* rendering/camera.h:8-15 */
+/* ======================================================================================================================= */
+/* PART 1: the reference's interface                                                                                        */
 
-/* PtRayHit, path_tracer.h:24-31 */
-typedef struct PtRayHit { float4 wuvt; float4 normal; i32 type; i32 iVert; uint32_t flags; } PtRayHit;
-/* PtResult, path_tracer.h:54-59 */
-typedef struct PtResult { float3 color; float3 albedo; float3 normal; } PtResult;
-/* PtResults, path_tracer.h:61-65 (caller frees with PtResults_Del: there is no Temp_ frame arena here) */
-typedef struct PtResults { float4* colors; float4* directions; } PtResults;
+typedef struct PtScene_s PtScene;         /* opaque, path_tracer.h:13 */
 
-/* PtTrace, path_tracer.h:44-52: host float3 images the caller reads after Pt_Trace (running mean) */
-typedef struct PtTrace
+/* Camera, rendering/camera.h:8-15 */
+typedef struct Camera_s { float4 position; quat rotation; float zNear; float zFar; float fovy; } Camera;
+
+typedef enum { PtHit_Nothing = 0, PtHit_Backface, PtHit_Triangle, PtHit_COUNT } PtHitType;     /* path_tracer.h:15-22 */
+typedef struct PtRayHit_s { float4 wuvt; float4 normal; PtHitType type; i32 iVert; u32 flags; } PtRayHit;     /* :24-31 */
+typedef struct PtDofInfo_s      /* :33-42 */
 {
-    float3* color;
-    float3* albedo;
-    float3* normal;
-    float3* denoised;
-    int2 imageSize;
-    float sampleWeight;
-    /* build-side state */
-    PimTrace* gpu;            /* the HBM-resident copies */
-    uint32_t sampleIndex;     /* index of the next sample; seeds the per-pixel streams */
-    uint32_t seed;
-    i32 maxBounces;           /* <= 0: the reference's roulette-only termination */
-    float frameDt;            /* Time_Deltaf() for DofUpdate */
+    float aperture; float focalLength; i32 bladeCount; float bladeRot; float focalPlaneCurvature; float autoFocusSpeed; bool autoFocus;
+} PtDofInfo;
+typedef struct PtTrace_s        /* :44-52: host float3 images the caller reads right after Pt_Trace (running mean) */
+{
+    float3* color; float3* albedo; float3* normal; float3* denoised; int2 imageSize; float sampleWeight;
 } PtTrace;
+typedef struct PtResult_s { float3 color; float3 albedo; float3 normal; } PtResult;           /* :54-59 */
+typedef struct PtResults_s { float4* colors; float4* directions; } PtResults;                 /* :61-65 */
 
-/* Lightmap / LmPack, rendering/lightmap.h:27-44 (the fields BakeFn touches) */
-typedef struct Lightmap { float4* probes[5]; float3* position; float3* normal; float* sampleCounts; i32 size; } Lightmap;
-/* Cubemap (rendering/cubemap.h:28-34; the convolved mips are not on this path) and AmbCube_t (math/types.h:513-517) */
-typedef struct Cubemap { i32 size; float3* color[6]; } Cubemap;
-typedef struct AmbCube_t { float4 Values[6]; } AmbCube_t;
-typedef struct LmPack { Lightmap* lightmaps; i32 lmCount; i32 lmSize; float texelsPerMeter; } LmPack;
+void PtSys_Init(void);                                   /* path_tracer.h:67, path_tracer.c:421-434 */
+void PtSys_Update(void);                                 /* :68 (frees what the frame's Pt_RayGen calls returned: MemSys_Update's role, main.c:90) */
+void PtSys_Shutdown(void);                               /* :69 */
 
-bool PtSys_Init(void);                                   /* path_tracer.c:421-434 */
-void PtSys_Shutdown(void);                               /* :439-446 */
-const char* PtSys_LastError(void);
+PtScene* PtScene_New(void);                              /* :71, path_tracer.c:1083-1093 */
+void PtScene_Update(PtScene* scene);                     /* :72, path_tracer.c:1023-1037 */
+void PtScene_Del(PtScene* scene);                        /* :73 */
+void PtScene_Gui(PtScene* scene);                        /* :74: the igText lines of path_tracer.c:1104-1115, printed to stdout */
 
-PtScene* PtScene_New(const PimSceneDesc* snapshot);      /* :1083-1093 */
-/* FlattenDrawables (path_tracer.c:692-782) + PtScene_Init: the first five fields of `rest` (vertCount, matCount, positions,
- * normals, uvs, matIds, materials) are ignored and filled from the GPU-flattened draw table */
-PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneDesc* rest);
-void PtScene_Update(PtScene* scene);                     /* :1023-1037 (UpdateDists; a changed scene is a new snapshot) */
-void PtScene_Del(PtScene* scene);                        /* :1095-1102 */
+void PtTrace_New(PtTrace* trace, int2 imageSize);        /* :76, path_tracer.c:1117-1131 */
+void PtTrace_Del(PtTrace* trace);                        /* :77 */
 
-/* BrdfLut, math/lighting.h:45-55; BrdfLut_New / BrdfLut_Update / BrdfLut_Del, math/lighting.c:86-118.  seed: the per-texel
- * streams */
-typedef struct { float x, y; } float2;
-typedef struct BrdfLut { int2 size; float2* texels; } BrdfLut;
-BrdfLut BrdfLut_New(int2 size, i32 numSamples, uint32_t seed);
-void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples, uint32_t seed);
+void DofInfo_New(PtDofInfo* dof);                        /* :79, path_tracer.c:1141-1153 */
+void DofInfo_Gui(PtDofInfo* dof);                        /* :80: sliders in the reference; the values, printed to stdout, here */
+
+PtRayHit Pt_Intersect(const PtScene* scene, float4 ro, float4 rd, float tNear, float tFar);   /* :82-87 */
+PtResult Pt_TraceRay(PtScene* scene, float4 ro, float4 rd);                                    /* :89-92 */
+void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* camera);           /* :94-98 */
+PtResults Pt_RayGen(PtScene* scene, float4 origin, i32 count);                                 /* :100-103; valid until PtSys_Update */
+
+/* rendering/lightmap.h:11-72 (vkrTextureId: rendering/vulkan/vkr.h:125-131) */
+#define kGiDirections 5
+typedef struct vkrTextureId_s { u32 version : 8; u32 type : 3; u32 index : 21; } vkrTextureId;
+typedef struct Lightmap_s
+{
+    float4* probes[kGiDirections]; float3* position; float3* normal; float* sampleCounts; i32 size; vkrTextureId slot;
+} Lightmap;
+typedef struct LmPack_s { float4 axii[kGiDirections]; Lightmap* lightmaps; i32 lmCount; i32 lmSize; float texelsPerMeter; } LmPack;
+void Lightmap_New(Lightmap* lm, i32 size);               /* lightmap.h:56, lightmap.c:81-133 (the Vulkan slot stays zero: the renderer's) */
+void Lightmap_Del(Lightmap* lm);                         /* :57 */
+LmPack* LmPack_Get(void);                                /* :61: the pack LmPack_Bake works on (ms_pack, lightmap.c:79) */
+void LmPack_Del(LmPack* pack);                           /* :67 */
+void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp);   /* :69, lightmap.c:1204-1223 */
+
+/* rendering/cubemap.h:28-34,209-213 and math/types.h:513-517, math/ambcube.h:69-74 */
+typedef struct Cubemap_s { i32 size; i32 mipCount; float3* color[6]; float4* convolved[6]; } Cubemap;
+typedef struct AmbCube_s { float4 Values[6]; } AmbCube_t;
+void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight);
+i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount);
+
+/* math/lighting.h:45-55, math/types.h:503-509; BrdfLut_New / BrdfLut_Update / BrdfLut_Del, math/lighting.c:86-118 */
+typedef struct BrdfLut_s { int2 size; float2* texels; } BrdfLut;
+BrdfLut BrdfLut_New(int2 size, i32 numSamples);
 void BrdfLut_Del(BrdfLut* lut);
+void BrdfLut_Update(BrdfLut* lut, i32 prevSamples, i32 newSamples);
 
-void PtTrace_New(PtTrace* trace, int2 imageSize);        /* :1117-1131 */
-void PtTrace_Del(PtTrace* trace);                        /* :1133-1139 */
-void DofInfo_New(PtDofInfo* dof);                        /* :1141-1153 */
+/* ======================================================================================================================= */
+/* PART 2: extensions -- what the reference takes from global singletons or per-thread state                                */
 
-PtRayHit Pt_Intersect(PtScene* scene, float4 ro, float4 rd, float tNear, float tFar);      /* :1466-1474 */
-PtResult Pt_TraceRay(PtScene* scene, float4 ro, float4 rd, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);   /* :2306-2416 */
-void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* camera);       /* :2557-2585 */
-PtResults Pt_RayGen(PtScene* scene, float4 origin, i32 count, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);   /* :2614-2644 */
-void PtResults_Del(PtResults* results);
-/* Cubemap_Bake, rendering/cubemap.h:209-213 / cubemap.c:162-190; AmbCube_Bake, math/ambcube.h:69-74 / ambcube.c:5-32.
- * sampleIndex / seed / maxBounces: the per-work-item streams and the optional bounce clamp */
-void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
-i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
+const char* PtSys_LastError(void);
+bool PtSys_Ok(void);                                     /* PtSys_Init succeeded (the reference asserts) */
 
-/* Lightmap_New / Lightmap_Del, rendering/lightmap.c:81-133: the single zeroed allocation per page (the Vulkan texture
- * slot and upload are the renderer's); texId stands for Lightmap.slot.index (lightmap.h:30) */
-void Lightmap_New(Lightmap* lm, i32 size);
-void Lightmap_Del(Lightmap* lm);
+/* The snapshot provider: fills *out from the engine's singletons and returns true; *modtime = Entities_Get()->modtime.
+ * The arrays it points to must stay valid until the provider is called again (PtScene_New / a PtScene_Update that finds a
+ * new modtime copy them to HBM before returning).  peekModtime != 0: only *modtime is wanted. */
+typedef bool (*PtSceneProviderFn)(PimSceneDesc* out, uint64_t* modtime, int peekModtime, void* user);
+void PtSys_SetSceneProvider(PtSceneProviderFn fn, void* user);
+
+typedef struct PtSysConfig
+{
+    uint32_t seed;            /* of every per-work-item Prng stream */
+    i32 maxBounces;           /* <= 0: the reference's termination, russian roulette only */
+    float frameDt;            /* Time_Deltaf() as DofUpdate sees it (path_tracer.c:2497); <= 0: 1/60 s */
+    i32 downloadAovs;         /* 0: Pt_Trace brings back `color` only; albedo / normal (read by the denoiser alone,
+                                 render_system.c:306-324) are fetched by PtTrace_DownloadAovs on demand.  Default 1. */
+    i32 device;               /* HIP device; < 0: environment PIM_GPU_DEVICE, else 0 */
+} PtSysConfig;
+void PtSys_Configure(const PtSysConfig* config);         /* before or after PtSys_Init; also resets the call counters below */
+/* the counters that stand in for the reference's ever-advancing per-thread streams: index of the next Pt_Trace sample,
+ * Pt_TraceRay stream, Pt_RayGen / AmbCube_Bake batch, Cubemap_Bake pass, LmPack_Bake pass */
+typedef struct PtSysCounters { uint32_t trace, traceRay, rayGen, cubemap, lmBake; } PtSysCounters;
+void PtSys_GetCounters(PtSysCounters* out);
+void PtTrace_DownloadAovs(PtTrace* trace);               /* with downloadAovs == 0: bring albedo / normal up to date now */
+
+/* explicit-argument forms (tests, tools): the same work with the counters' values passed in */
+PtScene* PtScene_NewFromSnapshot(const PimSceneDesc* snapshot);
+/* FlattenDrawables (path_tracer.c:692-782) + PtScene_Init: the vertex / material fields of `rest` are ignored and filled
+ * from the GPU-flattened draw table */
+PtScene* PtScene_NewFromDrawables(const PimDrawables* drawables, const PimSceneDesc* rest);
+PimScene* PtScene_Gpu(const PtScene* scene);             /* the C-ABI handle behind the scene */
+PtResult Pt_TraceRayEx(PtScene* scene, float4 ro, float4 rd, uint32_t sampleIndex, uint32_t seed, i32 maxBounces);
 /* EmbedAttributes, rendering/lightmap.c:1034-1045, the last step of LmPack_Pack (:1092): fills position / normal /
  * sampleCounts of every page from the draw table's uvs.zw and texIndices.w; texIds[lmCount] = the pages' texture ids
  * (NULL: page i has id i) */
 void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, const i32* texIds, i32 lmCount);
-/* rendering/lightmap.c:1204-1223; pages must be the reference's single allocation per lightmap (probes[0] = base) */
-void LmPack_Bake(PtScene* scene, LmPack* pack, float timeSlice, i32 spp, uint32_t passIndex, uint32_t seed, i32 maxBounces);
 
 #ifdef __cplusplus
 }

@@ -73,3 +73,47 @@ def test_texel_tiles_partition():
                 assert b % (64 * 64) == 0 or b == total
                 seen += e - b; prev_end = e
             assert seen == total
+
+
+def test_sample_ranges_and_tiles_partition():
+    for total in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                b, e = pdist.sample_range(r, world, total)
+                got += list(range(b, e))
+                assert abs((e - b) - total / world) < 1.0
+            assert got == list(range(total))
+    for lm_count, lm_size in ((1, 64), (3, 1024), (2, 100)):
+        per_row = (lm_size + 63) // 64
+        for world in (1, 2, 8):
+            tiles = sorted(t for r in range(world) for t in pdist.tiles_of(r, world, lm_count, lm_size))
+            assert tiles == list(range(lm_count * per_row * per_row))
+            counts = [len(pdist.tiles_of(r, world, lm_count, lm_size)) for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+
+
+def _worker_unequal(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 5
+    b, e = pdist.sample_range(rank, world, total)
+    t = torch.from_numpy(_render(list(range(b, e))).copy())
+    pdist.reduce_mean_image(t, world, dist, dst=0, weight=e - b, total=total)
+    if rank == 0:
+        np.save(out, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_with_a_remainder_world2(tmp_path):
+    """--total-spp 5 on 2 ranks: 3 + 2 samples, weighted sum == the mean of all five samples (fp32 reassociation aside)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker_unequal, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    a, b = _render([0, 1, 2]), _render([3, 4])
+    want = a * np.float32(3.0 / 5.0) + b * np.float32(2.0 / 5.0)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert got.mean() > 0.01

@@ -1,12 +1,20 @@
-"""-m gpu: the plain-C host layer (pim_amd/host/pim_host.c: Pim's own entry-point names over the C-ABI)
-gives the same bits as the oracle: Pt_Trace's host images after several frames, Pt_Intersect, Pt_TraceRay."""
+"""-m gpu: the plain-C host layer (pim_amd/host/pim_host.c: Pim's own entry-point names AND signatures over the C-ABI).
+
+test_reference_caller_*: tests/host/ref_caller.c, a C program that declares the reference's prototypes and structs itself
+(rendering/path_tracer.h:13-103, lightmap.h:27-69, cubemap.h, ambcube.h) and never sees pim_host.h, is linked against
+libpimhost.so and run; everything it computes -- Pt_Trace's host images after three progressive frames, the autofocus
+state, Pt_Intersect, Pt_TraceRay, Pt_RayGen, Cubemap_Bake, AmbCube_Bake, two LmPack_Bake passes, the rebuild on a changed
+modtime -- equals the oracle's bits (portable-libm variant), replayed here in the same order."""
 import ctypes as C
 import os
+import struct
+import subprocess
 
 import numpy as np
 import pytest
 
 from pim_amd import api, scenes
+from tests.gpu_util import assert_bits_equal
 from tests.util import OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -23,8 +31,7 @@ class Int2(C.Structure):
 
 class PtTrace(C.Structure):
     _fields_ = [("color", C.c_void_p), ("albedo", C.c_void_p), ("normal", C.c_void_p), ("denoised", C.c_void_p),
-                ("imageSize", Int2), ("sampleWeight", C.c_float), ("gpu", C.c_void_p), ("sampleIndex", C.c_uint32),
-                ("seed", C.c_uint32), ("maxBounces", C.c_int32), ("frameDt", C.c_float)]
+                ("imageSize", Int2), ("sampleWeight", C.c_float)]
 
 
 class PtRayHit(C.Structure):
@@ -35,82 +42,110 @@ class PtResult(C.Structure):
     _fields_ = [("color", C.c_float * 3), ("albedo", C.c_float * 3), ("normal", C.c_float * 3)]
 
 
-def test_pim_named_entry_points_match_oracle():
-    host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
-    host.PtSys_Init.restype = C.c_bool
-    host.PtScene_New.restype = C.c_void_p
-    host.Pt_Intersect.restype = PtRayHit
-    host.Pt_Intersect.argtypes = [C.c_void_p, Float4, Float4, C.c_float, C.c_float]
-    host.Pt_TraceRay.restype = PtResult
-    host.Pt_TraceRay.argtypes = [C.c_void_p, Float4, Float4, C.c_uint32, C.c_uint32, C.c_int32]
-    assert host.PtSys_Init()
+def write_scene_file(path, sc, cam):
+    """the scene snapshot + camera as tests/host/ref_caller.c reads them"""
+    d = sc.desc
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8i", 0x53434E45, d.vertCount, d.matCount, d.texCount, d.skySize, d.brdfLutSize, d.emissiveAttempts, d.seed))
+        f.write(struct.pack("<f", d.metersPerCell)); f.write(bytes(d.media)); f.write(bytes(cam))
+        f.write(sc.positions.tobytes()); f.write(sc.normals.tobytes()); f.write(sc.uvs.tobytes()); f.write(sc.matIds.tobytes())
+        f.write(bytes(sc.materials)[:48 * d.matCount])
+        for i in range(d.texCount):
+            t = sc.textures[i]
+            f.write(struct.pack("<3i", t.width, t.height, t.format)); f.write(sc.tex_arrays[i].tobytes())
+        if d.skySize > 0:
+            for k in range(6):
+                f.write(sc.sky[k].tobytes())
+        f.write(sc.lut.tobytes())
+
+
+def test_reference_caller_gets_the_oracles_bits(tmp_path):
+    exe = os.path.join(ROOT, "pim_amd", "host", "build", "ref_caller")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pim_amd", "host")])
     sc = scenes.cornell_box()
-    scene = C.c_void_p(host.PtScene_New(C.byref(sc.desc)))
-    assert scene
-    o = OracleScene(sc.desc, accel=1)
-    W, H = 80, 45
-    trace = PtTrace()
-    host.PtTrace_New(C.byref(trace), Int2(W, H))
-    trace.seed, trace.maxBounces = 17, 4
-    dof, dof_o = api.PimDofInfo(), scenes.default_dof()
-    host.DofInfo_New(C.byref(dof))
-    assert bytes(dof) == bytes(dof_o)
     cam = scenes.pt_test_camera()
+    scene_path, out_path = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
+    write_scene_file(scene_path, sc, cam)
+    run = subprocess.run([exe, scene_path, out_path], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "ref_caller ok" in run.stdout and "Vertex Count: 324" in run.stdout and "Emissive Count: 12" in run.stdout      # PtScene_Gui
+    assert "Blade Count: 5" in run.stdout                                                                                # DofInfo_Gui
+    data = open(out_path, "rb").read()
+    off = 0
+
+    def take(count, dtype=np.float32):
+        nonlocal off
+        a = np.frombuffer(data, dtype, count, off); off += a.nbytes
+        return a
+
+    # ---- the same calls, in the same order, on the oracle (PtSys_Configure: seed 17, 4 bounces, dt 1/60) ----
+    o = OracleScene(sc.desc, accel=1)
+    W, H, seed, mb = 80, 45, 17, 4
     img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dof = scenes.default_dof()
     for s in range(3):
-        trace.sampleWeight = 1.0 / (s + 1)
-        host.Pt_Trace(C.byref(trace), C.byref(dof), scene, C.byref(cam))
-        o.trace_image(img, W, H, cam, dof_o, scenes.trace_params(s, seed=17, max_bounces=4))
-    color = np.ctypeslib.as_array(C.cast(trace.color, C.POINTER(C.c_float)), shape=(W * H, 3))
-    assert (color.view(np.uint32) == img[0].view(np.uint32)).all()
-    assert trace.sampleIndex == 3
-
-    ro = Float4(0.5, -1.0, 0.25, 0.0); rd = Float4(0.0, 0.6, 0.8, 0.0)
-    h = host.Pt_Intersect(scene, ro, rd, 0.0, api.RCP_EPSILON)
-    ho = o.intersect(np.array([[0.5, -1.0, 0.25, 0.0]], np.float32), np.array([[0.0, 0.6, 0.8, 0.0]], np.float32))[0]
-    assert h.type == ho["type"] and h.iVert == ho["iVert"] and np.float32(h.wuvt.w) == ho["wuvt"][3]
-    r = host.Pt_TraceRay(scene, ro, rd, 2, 5, 4)
-    r_o = o.trace_rays(np.array([[0.5, -1.0, 0.25, 0.0]], np.float32), np.array([[0.0, 0.6, 0.8, 0.0]], np.float32), 2, 5, 4)[0]
-    assert tuple(np.float32(v) for v in r.color) == tuple(r_o["color"])
-
-    # Cubemap_Bake / AmbCube_Bake under their own names (rendering/cubemap.h:209, math/ambcube.h:69)
-    class Cubemap(C.Structure):
-        _fields_ = [("size", C.c_int32), ("color", C.c_void_p * 6)]
-    size = 8
-    fg = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
-    fo = [np.zeros(size * size * 3, np.float32) for _ in range(6)]
-    cm = Cubemap(); cm.size = size
+        o.trace_image(img, W, H, cam, dof, scenes.trace_params(s, seed=seed, max_bounces=mb))      # Pt_Trace call k = sample k
+    for k, name in enumerate(("color", "albedo", "normal")):
+        assert_bits_equal(take(W * H * 3).reshape(-1, 3), img[k], name)
+    got_dof = take(7)
+    assert got_dof[1] == np.float32(dof.focalLength) and got_dof.view(np.uint8)[24] == 1
+    ro = np.array([[0.5, -1.0, 0.25, 0.0]], np.float32); rd = np.array([[0.0, 0.6, 0.8, 0.0]], np.float32)
+    ho = o.intersect(ro, rd)
+    hit = np.frombuffer(data, api.RAYHIT_DTYPE, 1, off); off += 48
+    for fld in ("wuvt", "normal", "type", "iVert", "flags"):
+        assert_bits_equal(hit[fld], ho[fld], "Pt_Intersect " + fld)
+    for k in range(3):                                                                           # Pt_TraceRay call k = stream k
+        r = np.frombuffer(data, api.RESULT_DTYPE, 1, off); off += 36
+        want = o.trace_rays(ro, rd, sampleIndex=k, seed=seed, maxBounces=mb)
+        for fld in ("color", "albedo", "normal"):
+            assert_bits_equal(r[fld], want[fld], f"Pt_TraceRay {k} {fld}")
+    origin = np.array([0.25, -0.5, 0.5, 0.0], np.float32)
+    co, do = o.raygen(origin, 256, sampleIndex=0, seed=seed, maxBounces=mb)
+    assert_bits_equal(take(256 * 4).reshape(-1, 4), co, "Pt_RayGen colors"); assert_bits_equal(take(256 * 4).reshape(-1, 4), do, "Pt_RayGen directions")
+    fo = [np.zeros(64 * 3, np.float32) for _ in range(6)]
+    o.cubemap_bake(fo, 8, origin, 1.0, sampleIndex=0, seed=seed, maxBounces=mb)
     for f in range(6):
-        cm.color[f] = fg[f].ctypes.data
-    origin = Float4(0.25, -0.5, 0.5, 0.0)
-    host.Cubemap_Bake.argtypes = [C.c_void_p, C.c_void_p, Float4, C.c_float, C.c_uint32, C.c_uint32, C.c_int32]
-    host.Cubemap_Bake(C.byref(cm), scene, origin, 1.0, 0, 3, 4)
-    o.cubemap_bake(fo, size, np.array([0.25, -0.5, 0.5, 0.0], np.float32), 1.0, sampleIndex=0, seed=3, maxBounces=4)
-    assert all((a.view(np.uint32) == b.view(np.uint32)).all() for a, b in zip(fg, fo))
-    cube_g = np.zeros((6, 4), np.float32); cube_o = np.zeros((6, 4), np.float32)
-    host.AmbCube_Bake.restype = C.c_int32
-    host.AmbCube_Bake.argtypes = [C.c_void_p, C.c_void_p, Float4, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32]
-    n = host.AmbCube_Bake(scene, cube_g.ctypes.data_as(C.c_void_p), origin, 200, 0, 1, 3, 4)
-    assert n == 1 == o.ambcube_bake(cube_o, np.array([0.25, -0.5, 0.5, 0.0], np.float32), 200, 0, sampleIndex=1, seed=3, maxBounces=4)
-    assert (cube_g.view(np.uint32) == cube_o.view(np.uint32)).all()
-    host.PtTrace_Del(C.byref(trace))
-    host.PtScene_Del(scene)
+        assert_bits_equal(take(64 * 3), fo[f], f"Cubemap_Bake face {f}")
+    cube = np.zeros((6, 4), np.float32)
+    n = o.ambcube_bake(cube, origin, 200, 0, sampleIndex=1, seed=seed, maxBounces=mb)               # the second Pt_RayGen batch
+    assert_bits_equal(take(24).reshape(6, 4), cube, "AmbCube_Bake"); assert take(1, np.int32)[0] == n == 1
+    S = 32
+    page = np.zeros(S * S * 27, np.float32)
+    pos = page[S * S * 20:S * S * 23].reshape(S, S, 3); nor = page[S * S * 23:S * S * 26].reshape(S, S, 3); cnt = page[S * S * 26:].reshape(S, S)
+    ys, xs = np.meshgrid(np.arange(4, 28), np.arange(4, 28), indexing="ij")
+    pos[4:28, 4:28, 0] = np.float32(-3.0) + np.float32(0.25) * xs.astype(np.float32); pos[4:28, 4:28, 1] = -4.95
+    pos[4:28, 4:28, 2] = np.float32(-3.0) + np.float32(0.25) * ys.astype(np.float32)
+    nor[4:28, 4:28, 1] = 1.0; cnt[4:28, 4:28] = 1.0
+    o.lightmap_bake([page], S, 4.0, 1.0, 3, passIndex=0, seed=seed, maxBounces=mb)
+    o.lightmap_bake([page], S, 4.0, 0.5, 2, passIndex=1, seed=seed, maxBounces=mb)
+    got_page = take(S * S * 27)
+    assert_bits_equal(got_page, page, "LmPack_Bake page")
+    assert (got_page[:S * S * 4] != 0).any() and got_page[S * S * 26:].max() >= 4.0
+    hit2 = np.frombuffer(data, api.RAYHIT_DTYPE, 1, off); off += 48
+    assert hit2.tobytes() == hit.tobytes()                          # the rebuilt scene answers alike
+    same, rebuilt, sz_trace, sz_lm = take(4, np.int32)
+    assert (same, rebuilt) == (0, 1) and sz_trace == 48 and sz_lm == 72
+    assert off == len(data)
 
 
 def test_scene_producers_under_pim_names():
     """FlattenDrawables + PtScene_New (PtScene_NewFromDrawables) and BrdfLut_New / BrdfLut_Update (math/lighting.c:86-118)
     through the plain-C host layer: same bits as the C-ABI calls they wrap"""
     host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
-    host.PtSys_Init.restype = C.c_bool
-    assert host.PtSys_Init()
+    host.PtSys_Ok.restype = C.c_bool
+    cfg = (C.c_int32 * 5)(7, 0, 0, 1, -1)                 # PtSysConfig: seed 7
+    host.PtSys_Configure(cfg)
+    host.PtSys_Init()
+    assert host.PtSys_Ok()
 
     class BrdfLut(C.Structure):
         _fields_ = [("size", Int2), ("texels", C.POINTER(C.c_float))]
     host.BrdfLut_New.restype = BrdfLut
-    host.BrdfLut_New.argtypes = [Int2, C.c_int32, C.c_uint32]
-    lut = host.BrdfLut_New(Int2(32, 32), 48, 7)
+    host.BrdfLut_New.argtypes = [Int2, C.c_int32]
+    lut = host.BrdfLut_New(Int2(32, 32), 48)
     assert lut.texels and lut.size.x == 32
-    host.BrdfLut_Update(C.byref(lut), 48, 64, C.c_uint32(7))
+    host.BrdfLut_Update(C.byref(lut), 48, 64)
     table = np.ctypeslib.as_array(lut.texels, shape=(32, 32, 2)).copy()
     want = np.zeros((32, 32, 2), np.float32)
     api.brdf_lut_bake(want, 0, 48, seed=7); api.brdf_lut_bake(want, 48, 64, seed=7)
@@ -124,7 +159,8 @@ def test_scene_producers_under_pim_names():
     scene = C.c_void_p(host.PtScene_NewFromDrawables(C.byref(dr.desc), C.byref(rest)))
     assert scene
     info = api.PimSceneInfo()
-    assert api.load_library().pimgpu_scene_info(scene, C.byref(info)) == 0
+    host.PtScene_Gpu.restype = C.c_void_p
+    assert api.load_library().pimgpu_scene_info(C.c_void_p(host.PtScene_Gpu(scene)), C.byref(info)) == 0
     assert info.triCount == 108 and info.matCount == 9 and info.emissiveCount == 12
     host.Pt_Intersect.restype = PtRayHit
     host.Pt_Intersect.argtypes = [C.c_void_p, Float4, Float4, C.c_float, C.c_float]
@@ -140,12 +176,13 @@ def test_lightmap_pages_under_pim_names():
     the plain-C host layer: the same bits as the C-ABI call it wraps, probes left zero"""
     from tests import prepare_util as pu
     host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
-    host.PtSys_Init.restype = C.c_bool
-    assert host.PtSys_Init()
+    host.PtSys_Ok.restype = C.c_bool
+    host.PtSys_Init()
+    assert host.PtSys_Ok()
 
     class Lightmap(C.Structure):
         _fields_ = [("probes", C.POINTER(C.c_float) * 5), ("position", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)),
-                    ("sampleCounts", C.POINTER(C.c_float)), ("size", C.c_int32)]
+                    ("sampleCounts", C.POINTER(C.c_float)), ("size", C.c_int32), ("slot", C.c_uint32)]
     S, ids = 48, [9, 4]
     lms = (Lightmap * 2)()
     for lm in lms:
