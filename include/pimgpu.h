@@ -206,6 +206,14 @@ typedef struct PimTrace PimTrace;  /* device-side PtTrace (path_tracer.h:44-52) 
 
 /* PtSys_Init / PtSys_Shutdown (path_tracer.c:421-446): select the HIP device. */
 int pimgpu_init(int device);
+/* The same with a device LIST: the reference fans every entry point out over all host threads inside one process
+ * (Task_Run over Thread_HardwareCount() threads, threading/task.c:213-223); this fans out over the listed GPUs.  Every scene
+ * is replicated on each device; pimgpu_trace_image renders one band of rows per device, pimgpu_lightmap_bake 64x64-texel tiles
+ * round-robin; results land in the caller's host buffers (each device copies its own share), the light histograms of the
+ * replicas are summed before every UpdateDists.  Sharding does not change a bit of any result.  The other entry points run
+ * on the first device.  A device may be listed more than once (two contexts on one GPU).  pimgpu_init(d) == a list of one. */
+int pimgpu_init_devices(const int* devices, int deviceCount);
+int pimgpu_device_count(void);           /* entries of the list in use, 0 before init */
 int pimgpu_shutdown(void);
 const char* pimgpu_last_error(void);
 /* Host memory for the buffers a caller reads right after a call (PtTrace's images, Tex_Calloc in PtTrace_New,

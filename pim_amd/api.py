@@ -117,7 +117,7 @@ EXPORTS = [
     "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
-    "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc",
+    "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc", "pimgpu_init_devices", "pimgpu_device_count",
 ]
 
 _LIB = None
@@ -437,6 +437,12 @@ def work_counters(enable):
 
 def init(device=0):
     check(load_library().pimgpu_init(C.c_int(device)), "pimgpu_init")
+
+
+def init_devices(devices):
+    """pimgpu_init_devices: one context per entry of the list (a device may repeat)"""
+    arr = (C.c_int * len(devices))(*devices)
+    check(load_library().pimgpu_init_devices(arr, C.c_int(len(devices))), "pimgpu_init_devices")
 
 
 def shutdown():

@@ -11,11 +11,16 @@
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 
 namespace pt {
 
 static thread_local char g_error[512] = "";
-Library g_lib;
+Library g_libs[kMaxDevices];
+int g_libCount = 0;
+static thread_local Library* tl_lib = nullptr;
+Library& cur_lib() { return tl_lib ? *tl_lib : g_libs[0]; }
+void set_cur_lib(Library* lib) { tl_lib = lib; }
 
 void set_error(const char* fmt, ...)
 {
@@ -123,19 +128,77 @@ static int scene_build_bvh(PimScene* s)
     return PIMGPU_OK;
 }
 
+int for_each_context(int count, const std::function<int(int)>& fn)
+{
+    if (count <= 1) return fn(0);
+    std::vector<int> rcs((size_t)count, PIMGPU_OK);
+    std::vector<std::string> msgs((size_t)count);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < count; ++i)
+        threads.emplace_back([&, i]() {
+            DeviceScope scope(i);
+            rcs[(size_t)i] = fn(i);
+            if (rcs[(size_t)i]) msgs[(size_t)i] = g_error;       /* the worker's thread-local message */
+        });
+    for (auto& t : threads) t.join();
+    for (int i = 0; i < count; ++i)
+        if (rcs[(size_t)i]) { set_error("context %d (device %d): %s", i, g_libs[i].device, msgs[(size_t)i].c_str()); return rcs[(size_t)i]; }
+    return PIMGPU_OK;
+}
+
+/* live0 += liveD - base: the increments replica D made since the last UpdateDists */
+__global__ __launch_bounds__(256) void k_live_merge(uint32_t* __restrict__ live0, const uint32_t* __restrict__ liveD, const uint32_t* __restrict__ base, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) live0[i] += liveD[i] - base[i];
+}
+
+/*
+ * UpdateDists (path_tracer.c:2471-2483) with replicas.  LightOnHit's feedback (integer atomics into live[]) lands in the replica
+ * of the device that traced the path, so before Dist1D_Update runs the replicas' increments are summed: replica 0 adds
+ * (live_d - base) of every other replica, base being live[] as the last UpdateDists left it (identical everywhere), and
+ * the sum is copied back to all.  Every replica then runs the same update on the same numbers, so pdf / cdf stay
+ * identical on all devices AND identical to what ONE device tracing all the paths would hold: sharding does not change a
+ * bit of the result.  One replica: UpdateDists on the current stream, nothing else.
+ */
+int scene_update_dists_all(PimScene* scene)
+{
+    const int G = g_libCount;
+    if (G <= 1 || !scene->peers[1]) return update_dists(scene->d, g_lib.stream);
+    const int64_t n = (int64_t)scene->d.gridLen * scene->d.emissiveCount;
+    if (n <= 0) return PIMGPU_OK;
+    const size_t bytes = sizeof(uint32_t) * (size_t)n;
+    Library& L0 = g_libs[0];
+    for (int i = 1; i < G; ++i) { DeviceScope scope(i); PT_HIP(hipStreamSynchronize(g_libs[i].stream)); }
+    {
+        DeviceScope scope(0);
+        for (int i = 1; i < G; ++i)
+        {
+            PT_HIP(hipMemcpyAsync(scene->liveTmp, scene->peers[i]->live, bytes, hipMemcpyDeviceToDevice, L0.stream));
+            k_live_merge<<<(unsigned)((n + 255) / 256), 256, 0, L0.stream>>>(scene->live, scene->liveTmp, scene->liveBase, n);
+        }
+        for (int i = 1; i < G; ++i) PT_HIP(hipMemcpyAsync(scene->peers[i]->live, scene->live, bytes, hipMemcpyDeviceToDevice, L0.stream));
+        PT_HIP(hipStreamSynchronize(L0.stream));
+    }
+    int rc = for_each_context(G, [&](int i) {
+        PimScene* r = i == 0 ? scene : scene->peers[i];
+        int rc2 = update_dists(r->d, g_lib.stream);
+        if (!rc2 && i == 0 && hipMemcpyAsync(scene->liveBase, scene->live, bytes, hipMemcpyDeviceToDevice, g_lib.stream) != hipSuccess) rc2 = PIMGPU_E_DEVICE;
+        if (!rc2 && hipStreamSynchronize(g_lib.stream) != hipSuccess) rc2 = PIMGPU_E_DEVICE;
+        return rc2;
+    });
+    return rc;
+}
+
 } /* namespace pt */
 
 using namespace pt;
 
 extern "C" {
 
-int pimgpu_init(int device)
+/* one context: stream, traversal resources, scratch address; the device is current */
+static int init_context(Library& L, int device)
 {
-    if (g_lib.initialised) return PIMGPU_OK;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return PIMGPU_E_DEVICE; }
-    if (device < 0 || device >= count) { set_error("device %d out of range (have %d)", device, count); return PIMGPU_E_INVALID; }
-    PT_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     PT_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -143,15 +206,65 @@ int pimgpu_init(int device)
         set_error("device %d is %s; libpimgpu is built for gfx950 only", device, prop.gcnArchName);
         return PIMGPU_E_DEVICE;
     }
-    PT_HIP(hipStreamCreateWithFlags(&g_lib.stream, hipStreamNonBlocking));
-    g_lib.device = device;
-    g_lib.cuCount = prop.multiProcessorCount;
-    int rc = g_lib.trace.ensure();
+    PT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    L.device = device;
+    L.cuCount = prop.multiProcessorCount;
+    int rc = L.trace.ensure();
     if (rc) return rc;
     if ((rc = stddev_scratch_setup(device))) return rc;
-    g_lib.initialised = true;
+    L.initialised = true;
     return PIMGPU_OK;
 }
+
+int pimgpu_init_devices(const int* devices, int deviceCount)
+{
+    if (g_libs[0].initialised)
+    {
+        /* PtSys_Init twice is harmless in the reference too; a different list needs pimgpu_shutdown first */
+        bool same = deviceCount == g_libCount;
+        for (int i = 0; same && i < deviceCount; ++i) same = devices && devices[i] == g_libs[i].device;
+        if (same) return PIMGPU_OK;
+        set_error("init_devices: already initialised with another device list (pimgpu_shutdown first)");
+        return PIMGPU_E_STATE;
+    }
+    if (!devices || deviceCount < 1 || deviceCount > kMaxDevices) { set_error("init_devices: need 1..%d devices", kMaxDevices); return PIMGPU_E_INVALID; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return PIMGPU_E_DEVICE; }
+    for (int i = 0; i < deviceCount; ++i)
+        if (devices[i] < 0 || devices[i] >= count) { set_error("device %d out of range (have %d)", devices[i], count); return PIMGPU_E_INVALID; }
+    int rc = PIMGPU_OK;
+    for (int i = 0; i < deviceCount && !rc; ++i)
+    {
+        PT_HIP(hipSetDevice(devices[i]));
+        rc = init_context(g_libs[i], devices[i]);
+        /* replicas read each other's light histograms and image bands over xGMI */
+        for (int k = 0; k < i && !rc; ++k)
+            if (devices[k] != devices[i])
+            {
+                hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("no peer access from device %d to %d", devices[i], devices[k]); rc = PIMGPU_E_DEVICE; }
+                (void)hipGetLastError();
+                hipSetDevice(devices[k]);
+                e = hipDeviceEnablePeerAccess(devices[i], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !rc) { set_error("no peer access from device %d to %d", devices[k], devices[i]); rc = PIMGPU_E_DEVICE; }
+                (void)hipGetLastError();
+                hipSetDevice(devices[i]);
+            }
+    }
+    hipSetDevice(devices[0]);
+    if (rc)
+    {
+        for (int i = 0; i < deviceCount; ++i) if (g_libs[i].stream) { hipSetDevice(devices[i]); g_libs[i].trace.release(); hipStreamDestroy(g_libs[i].stream); g_libs[i] = Library(); }
+        return rc;
+    }
+    g_libCount = deviceCount;
+    set_cur_lib(nullptr);
+    return PIMGPU_OK;
+}
+
+int pimgpu_init(int device) { return pimgpu_init_devices(&device, 1); }
+
+int pimgpu_device_count(void) { return g_libs[0].initialised ? g_libCount : 0; }
 
 void* pimgpu_host_alloc(size_t bytes)
 {
@@ -168,14 +281,22 @@ void pimgpu_host_free(void* p)
 
 int pimgpu_shutdown(void)
 {
-    if (!g_lib.initialised) return PIMGPU_OK;
-    hipStreamSynchronize(g_lib.stream);
-    g_lib.release_groups();
-    g_lib.work.release();
-    g_lib.trace.release();
-    hipStreamDestroy(g_lib.stream);
-    g_lib.stream = nullptr;
-    g_lib.initialised = false;
+    if (!g_libs[0].initialised) return PIMGPU_OK;
+    set_cur_lib(nullptr);
+    for (int i = 0; i < g_libCount; ++i)
+    {
+        Library& L = g_libs[i];
+        if (!L.initialised) continue;
+        hipSetDevice(L.device);
+        DeviceScope scope(i);
+        hipStreamSynchronize(L.stream);
+        L.release_groups();
+        L.work.release();
+        L.trace.release();
+        hipStreamDestroy(L.stream);
+        L = Library();
+    }
+    g_libCount = 0;
     return PIMGPU_OK;
 }
 
@@ -201,7 +322,8 @@ int pimgpu_work_counters(int enable, uint64_t* out)
     return PIMGPU_OK;
 }
 
-int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
+/* one replica, in the current context */
+static int scene_create_one(const PimSceneDesc* d, PimScene** out)
 {
     if (out) *out = nullptr;
     int rc = check_ready(); if (rc) return rc;
@@ -341,10 +463,32 @@ int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
     return PIMGPU_OK;
 }
 
+int pimgpu_scene_create(const PimSceneDesc* d, PimScene** out)
+{
+    int rc = scene_create_one(d, out);
+    if (rc || g_libCount <= 1) return rc;
+    /* replicas: every context runs the same deterministic set-up on its own copy (scenes are small against 288 GB) */
+    PimScene* primary = *out;
+    rc = for_each_context(g_libCount, [&](int i) { return i == 0 ? PIMGPU_OK : scene_create_one(d, &primary->peers[i]); });
+    const size_t n = (size_t)primary->d.gridLen * (size_t)primary->d.emissiveCount;
+    if (!rc && (hipMalloc(&primary->liveBase, sizeof(uint32_t) * (n ? n : 1)) != hipSuccess || hipMalloc(&primary->liveTmp, sizeof(uint32_t) * (n ? n : 1)) != hipSuccess))
+    { set_error("scene_create: out of device memory"); rc = PIMGPU_E_NOMEM; }
+    if (!rc && n) { hipMemcpyAsync(primary->liveBase, primary->live, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, g_lib.stream); hipStreamSynchronize(g_lib.stream); }
+    if (rc) { pimgpu_scene_destroy(primary); *out = nullptr; }
+    return rc;
+}
+
 int pimgpu_scene_destroy(PimScene* scene)
 {
     if (!scene) return PIMGPU_OK;
+    for (int i = 1; i < kMaxDevices; ++i)
+        if (scene->peers[i])
+        {
+            if (i < g_libCount) { DeviceScope scope(i); hipStreamSynchronize(g_lib.stream); scene_free(scene->peers[i]); }
+            scene->peers[i] = nullptr;
+        }
     if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
+    hipFree(scene->liveBase); hipFree(scene->liveTmp);
     scene_free(scene);
     return PIMGPU_OK;
 }
@@ -353,6 +497,7 @@ int pimgpu_scene_rebuild_bvh(PimScene* scene)
 {
     int rc = check_ready(); if (rc) return rc;
     if (!scene) { set_error("scene_rebuild_bvh: NULL scene"); return PIMGPU_E_INVALID; }
+    if (g_libCount > 1 && scene->peers[1]) return for_each_context(g_libCount, [&](int i) { return scene_build_bvh(i == 0 ? scene : scene->peers[i]); });
     return scene_build_bvh(scene);
 }
 
@@ -360,7 +505,7 @@ int pimgpu_scene_update_dists(PimScene* scene)
 {
     int rc = check_ready(); if (rc) return rc;
     if (!scene) { set_error("scene_update_dists: NULL scene"); return PIMGPU_E_INVALID; }
-    if ((rc = update_dists(scene->d, g_lib.stream))) return rc;
+    if ((rc = scene_update_dists_all(scene))) return rc;
     PT_HIP(hipStreamSynchronize(g_lib.stream));
     return PIMGPU_OK;
 }
@@ -399,6 +544,18 @@ int pimgpu_scene_download_lights(const PimScene* s, int32_t* vertToEmit, int32_t
     if (pdf && L * E) PT_HIP(hipMemcpy(pdf, s->pdf, 4 * L * E, hipMemcpyDeviceToHost));
     if (cdf && L) PT_HIP(hipMemcpy(cdf, s->cdf, 4 * L * (E + 1), hipMemcpyDeviceToHost));
     if (live && L * E) PT_HIP(hipMemcpy(live, s->live, 4 * L * E, hipMemcpyDeviceToHost));
+    if (live && L * E && g_libCount > 1 && s->peers[1])
+    {
+        /* the histogram as ONE device would hold it: replica 0's plus the increments the other replicas made since the last UpdateDists */
+        std::vector<uint32_t> other(L * E), base(L * E);
+        PT_HIP(hipMemcpy(base.data(), s->liveBase, 4 * L * E, hipMemcpyDeviceToHost));
+        for (int i = 1; i < g_libCount; ++i)
+        {
+            { DeviceScope scope(i); PT_HIP(hipStreamSynchronize(g_lib.stream)); }
+            PT_HIP(hipMemcpy(other.data(), s->peers[i]->live, 4 * L * E, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < L * E; ++k) live[k] += other[k] - base[k];
+        }
+    }
     return PIMGPU_OK;
 }
 

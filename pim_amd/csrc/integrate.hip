@@ -245,6 +245,7 @@ struct CameraArgs
     int32_t width, height;
     uint32_t sampleIndex, seed;
     const float* focalDev;          /* non-null: dof.focalLength of this frame, left on the device by k_focus_update */
+    int32_t pixelBegin, pixelCount; /* the band of pixels this launch renders (multi-device: rows of the image) */
 };
 
 /* CalculateDof, pt.c:2418-2452 */
@@ -278,8 +279,9 @@ __global__ void k_focus_update(const DHit* __restrict__ hit, float focalLength, 
 /* TraceFn up to Pt_TraceRay, pt.c:2514-2545 */
 __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, float4* extD, int32_t* queue, CameraArgs c)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.width * c.height) return;
+    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;       /* path slot; pixel = pixelBegin + slot (a band of the image) */
+    if (slot >= c.pixelCount) return;
+    const int32_t i = c.pixelBegin + slot;
     const int32_t cx = i % c.width, cy = i / c.width;
     const float rcpX = 1.0f / (float)c.width, rcpY = 1.0f / (float)c.height;
     Ctx ctx = ctx_make();
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, 
     PimDofInfo dof = c.dof;
     if (c.focalDev) dof.focalLength = *c.focalDev;
     CalculateDof(ctx, dof, c.right, c.up, c.fwd, &ro, &rd);
-    path_start(ps, extO, extD, queue, i, ctx, ro, rd);
+    path_start(ps, extO, extD, queue, slot, ctx, ro, rd);
 }
 
 /* batched Pt_TraceRay: rays given (ro != null), RayGenFn's uniform sphere directions (pt.c:2596-2612), or the
@@ -809,12 +811,13 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
  * this covers maxBounces == 0 style early stops): not needed -- shade_b finishes every path at the limit. */
 
 /* TraceFn's accumulate, pt.c:2547-2552 */
-__global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restrict__ results, int32_t width, int32_t height, float sampleWeight,
+__global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restrict__ results, int32_t pixelBegin, int32_t pixelCount, float sampleWeight,
     float* __restrict__ color, float* __restrict__ albedo, float* __restrict__ normal)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width * height) return;
-    const PimResult r = results[i];
+    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= pixelCount) return;
+    const PimResult r = results[slot];
+    const int64_t i = (int64_t)pixelBegin + slot;
     for (int k = 0; k < 3; ++k)
     {
         color[i * 3 + k] = f1_lerp(color[i * 3 + k], r.color[k], sampleWeight);
@@ -1160,6 +1163,8 @@ int integrate_image(PimScene* scene, int32_t n, int32_t maxBounces, PimTraceStat
 
 using namespace pt;
 
+static thread_local bool g_makingPeer = false;     /* pimgpu_trace_create is making a peer copy: no recursion into the other contexts */
+
 extern "C" {
 
 int pimgpu_trace_create(int32_t width, int32_t height, PimTrace** out)
@@ -1176,12 +1181,31 @@ int pimgpu_trace_create(int32_t width, int32_t height, PimTrace** out)
         set_error("trace_create: out of device memory"); return PIMGPU_E_NOMEM;
     }
     *out = t;
-    return pimgpu_trace_clear(t);
+    if ((rc = pimgpu_trace_clear(t))) return rc;
+    if (g_libCount > 1 && !g_makingPeer)
+    {
+        /* one copy of the buffers per context; context i keeps its band of rows up to date */
+        rc = for_each_context(g_libCount, [&](int i) {
+            if (i == 0) return PIMGPU_OK;
+            g_makingPeer = true;
+            const int r = pimgpu_trace_create(width, height, &t->peers[i]);
+            g_makingPeer = false;
+            return r;
+        });
+        if (rc) { pimgpu_trace_destroy(t); *out = nullptr; }
+    }
+    return rc;
 }
 
 int pimgpu_trace_destroy(PimTrace* t)
 {
     if (!t) return PIMGPU_OK;
+    for (int i = 1; i < kMaxDevices; ++i)
+        if (t->peers[i])
+        {
+            PimTrace* peer = t->peers[i]; t->peers[i] = nullptr;
+            if (i < g_libCount) { DeviceScope scope(i); pimgpu_trace_destroy(peer); }
+        }
     if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
     hipFree(t->color); hipFree(t->albedo); hipFree(t->normal);
     delete t;
@@ -1198,16 +1222,19 @@ int pimgpu_trace_clear(PimTrace* t)
     PT_HIP(hipMemsetAsync(t->normal, 0, bytes, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));
     memset(&t->stats, 0, sizeof(t->stats));
+    t->gathered = true;
+    for (int i = 1; i < g_libCount; ++i)
+        if (t->peers[i]) { DeviceScope scope(i); if ((rc = pimgpu_trace_clear(t->peers[i]))) return rc; }
     return PIMGPU_OK;
 }
 
-int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p)
+/* one context renders the pixels [pixelBegin, pixelBegin + n) of the image into its copy of the PtTrace buffers */
+static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p, int32_t pixelBegin, int32_t n)
 {
     int rc = check_ready(); if (rc) return rc;
-    if (!scene || !t || !cam || !dof || !p) { set_error("trace_image: NULL argument"); return PIMGPU_E_INVALID; }
-    if (dof->bladeCount <= 0) { set_error("trace_image: dof.bladeCount must be positive"); return PIMGPU_E_INVALID; }
+    memset(&t->stats, 0, sizeof(t->stats));
+    if (n <= 0) return PIMGPU_OK;                         /* more contexts than rows */
     hipStream_t st = g_lib.stream;
-    const int32_t n = t->width * t->height;
     WorkBuffers& w = g_lib.work;
     if ((rc = w.ensure_paths(n))) return rc;
     if (!g_lib.frameBegin) { PT_HIP(hipEventCreate(&g_lib.frameBegin)); PT_HIP(hipEventCreate(&g_lib.frameEnd)); }
@@ -1240,11 +1267,12 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
         c.slope = f2_v(aspect * tn, tn);
     }
     c.dof = *dof; c.width = t->width; c.height = t->height; c.sampleIndex = p->sampleIndex; c.seed = p->seed; c.focalDev = focalDev;
-    k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
+    c.pixelBegin = pixelBegin; c.pixelCount = n;
+    if (n > 0) k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
     if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr, [&](hipStream_t s)
-        { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, t->width, t->height, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s);
+        { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, pixelBegin, n, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s);
           if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s); }))) return rc;
     PT_HIP(hipEventSynchronize(e1));
     dof->focalLength = focalHost;                                                  /* DofUpdate updates the caller's struct */
@@ -1255,8 +1283,86 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     return PIMGPU_OK;
 }
 
+int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !t || !cam || !dof || !p) { set_error("trace_image: NULL argument"); return PIMGPU_E_INVALID; }
+    if (dof->bladeCount <= 0) { set_error("trace_image: dof.bladeCount must be positive"); return PIMGPU_E_INVALID; }
+    const int G = g_libCount;
+    if (G <= 1 || !scene->peers[1] || !t->peers[1]) return trace_image_one(scene, t, cam, dof, p, 0, t->width * t->height);
+    /*
+     * Several devices: the image is cut into G bands of rows, context i renders band i with its replica of the scene into its
+     * copy of the buffers.  A pixel's path depends on nothing but its own Prng stream and the scene, and the light
+     * histograms are summed over the replicas before every UpdateDists (scene_update_dists_all), so the image equals the
+     * one-device image bit for bit.  No exchange step here: every device copies its own band to the host (pimgpu_trace_download).
+     */
+    if (p->updateDists) { if ((rc = scene_update_dists_all(scene))) return rc; }
+    PimTraceParams q = *p; q.updateDists = 0;
+    PimDofInfo dofs[kMaxDevices];
+    for (int i = 0; i < G; ++i) dofs[i] = *dof;
+    rc = for_each_context(G, [&](int i) {
+        int32_t r0, r1; band_of(t->height, i, G, &r0, &r1);
+        return trace_image_one(i == 0 ? scene : scene->peers[i], i == 0 ? t : t->peers[i], cam, &dofs[i], &q, r0 * t->width, (r1 - r0) * t->width);
+    });
+    if (rc) return rc;
+    *dof = dofs[0];                                       /* every context traced the same autofocus ray */
+    PimTraceStats sum = t->stats;
+    for (int i = 1; i < G; ++i)
+    {
+        const PimTraceStats& a = t->peers[i]->stats;
+        sum.extensionRays += a.extensionRays; sum.shadowRays += a.shadowRays; sum.otherRays += a.otherRays - (dof->autoFocus ? 1 : 0);
+        sum.paths += a.paths; sum.tailRays += a.tailRays; sum.wavefrontPathBounces += a.wavefrontPathBounces; sum.tailPaths += a.tailPaths;
+        sum.tailPathBounces += a.tailPathBounces; sum.traceLaunches += a.traceLaunches;
+        sum.bounces = std::max(sum.bounces, a.bounces);
+        /* device times: the slowest context is the frame */
+        sum.traceMs = std::max(sum.traceMs, a.traceMs); sum.totalMs = std::max(sum.totalMs, a.totalMs);
+        sum.shadeAMs = std::max(sum.shadeAMs, a.shadeAMs); sum.shadeBMs = std::max(sum.shadeBMs, a.shadeBMs); sum.tailMs = std::max(sum.tailMs, a.tailMs);
+    }
+    t->stats = sum;
+    t->gathered = false;
+    return PIMGPU_OK;
+}
+
+/* multi-device: bring every band into the copy of context 0 (stddev, device-side readers) */
+static int trace_gather(const PimTrace* t)
+{
+    const int G = g_libCount;
+    if (G <= 1 || !t->peers[1] || t->gathered) return PIMGPU_OK;
+    for (int i = 1; i < G; ++i)
+    {
+        int32_t r0, r1; band_of(t->height, i, G, &r0, &r1);
+        const size_t off = (size_t)r0 * t->width * 3, bytes = sizeof(float) * 3 * (size_t)(r1 - r0) * t->width;
+        if (!bytes) continue;
+        { DeviceScope scope(i); PT_HIP(hipStreamSynchronize(g_lib.stream)); }
+        const PimTrace* src = t->peers[i];
+        PT_HIP(hipMemcpyAsync(t->color + off, src->color + off, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+        PT_HIP(hipMemcpyAsync(t->albedo + off, src->albedo + off, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+        PT_HIP(hipMemcpyAsync(t->normal + off, src->normal + off, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    }
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    const_cast<PimTrace*>(t)->gathered = true;
+    return PIMGPU_OK;
+}
+
 int pimgpu_trace_download(const PimTrace* t, float* color, float* albedo, float* normal)
 {
+    if (t && g_libCount > 1 && t->peers[1] && !t->gathered)
+    {
+        /* every device sends its own band straight to the host images, all links at once */
+        int rc0 = check_ready(); if (rc0) return rc0;
+        return for_each_context(g_libCount, [&](int i) {
+            int32_t r0, r1; band_of(t->height, i, g_libCount, &r0, &r1);
+            const size_t off = (size_t)r0 * t->width * 3, bytes = sizeof(float) * 3 * (size_t)(r1 - r0) * t->width;
+            const PimTrace* src = i == 0 ? t : t->peers[i];
+            if (!bytes) return PIMGPU_OK;
+            if (color) PT_HIP(hipMemcpyAsync(color + off, src->color + off, bytes, hipMemcpyDeviceToHost, g_lib.stream));
+            if (albedo) PT_HIP(hipMemcpyAsync(albedo + off, src->albedo + off, bytes, hipMemcpyDeviceToHost, g_lib.stream));
+            if (normal) PT_HIP(hipMemcpyAsync(normal + off, src->normal + off, bytes, hipMemcpyDeviceToHost, g_lib.stream));
+            PT_HIP(hipStreamSynchronize(g_lib.stream));
+            return PIMGPU_OK;
+        });
+    }
+
     int rc = check_ready(); if (rc) return rc;
     if (!t) { set_error("trace_download: NULL trace"); return PIMGPU_E_INVALID; }
     const size_t bytes = sizeof(float) * 3 * (size_t)t->width * t->height;
@@ -1271,6 +1377,7 @@ int pimgpu_trace_copy_dev(const PimTrace* t, void* colorDst, void* albedoDst, vo
 {
     int rc = check_ready(); if (rc) return rc;
     if (!t) { set_error("trace_copy_dev: NULL trace"); return PIMGPU_E_INVALID; }
+    if ((rc = trace_gather(t))) return rc;
     const size_t bytes = sizeof(float) * 3 * (size_t)t->width * t->height;
     if (colorDst) PT_HIP(hipMemcpyAsync(colorDst, t->color, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
     if (albedoDst) PT_HIP(hipMemcpyAsync(albedoDst, t->albedo, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
@@ -1282,6 +1389,7 @@ int pimgpu_trace_copy_dev(const PimTrace* t, void* colorDst, void* albedoDst, vo
 int pimgpu_trace_buffers(const PimTrace* t, void** colorDev, void** albedoDev, void** normalDev)
 {
     if (!t) { set_error("trace_buffers: NULL trace"); return PIMGPU_E_INVALID; }
+    { const int rcg = trace_gather(t); if (rcg) return rcg; }
     if (colorDev) *colorDev = t->color;
     if (albedoDev) *albedoDev = t->albedo;
     if (normalDev) *normalDev = t->normal;
@@ -1292,6 +1400,7 @@ int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
 {
     int rc = check_ready(); if (rc) return rc;
     if (!t) { set_error("trace_stddev: NULL trace"); return PIMGPU_E_INVALID; }
+    if ((rc = trace_gather(t))) return rc;
     float* outDev = (float*)g_lib.trace.status + 16;       /* spare words of the status block */
     const int32_t len = t->width * t->height;
     WorkBuffers& w = g_lib.work;
@@ -1316,6 +1425,7 @@ int pimgpu_trace_stddev_noalloc(const PimTrace* t, float* meanOut, float* stddev
 {
     int rc = check_ready(); if (rc) return rc;
     if (!t) { set_error("trace_stddev_noalloc: NULL trace"); return PIMGPU_E_INVALID; }
+    if ((rc = trace_gather(t))) return rc;                  /* one context: nothing to do, nothing allocated */
     const int64_t len64 = (int64_t)t->width * t->height;
     if (len64 > kStddevNoAllocMaxPixels)
     {
@@ -1373,7 +1483,7 @@ static int trace_rays_common(PimScene* scene, const float* ro, const float* rd, 
         if (hipMalloc(&dirDev, sizeof(float4) * (size_t)n) != hipSuccess) { set_error("raygen: out of device memory"); return PIMGPU_E_NOMEM; }
         org = f4_v(origin[0], origin[1], origin[2], origin[3]);
         /* Pt_RayGen starts with PtScene_Update (pt.c:2625), which reaches UpdateDists (:1034); Pt_TraceRay alone does not */
-        if ((rc = update_dists(scene->d, st))) { cleanup(); return rc; }
+        if ((rc = scene_update_dists_all(scene))) { cleanup(); return rc; }
     }
     k_init_rays<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], roDev, rdDev, org, dirDev, n, sampleIndex, seed, 0);
     rc = integrate_paths(scene, n, maxBounces, nullptr, nullptr);
@@ -1454,7 +1564,7 @@ int pimgpu_ambcube_bake(PimScene* scene, float* cube, const float* origin, int32
         if (hipMalloc(&dirDev, sizeof(float4) * (size_t)samples) != hipSuccess || hipMalloc(&cubeDev, sizeof(float4) * 6) != hipSuccess)
         { hipFree(dirDev); set_error("ambcube_bake: out of device memory"); return PIMGPU_E_NOMEM; }
         hipMemcpyAsync(cubeDev, cube, sizeof(float4) * 6, hipMemcpyHostToDevice, st);
-        if ((rc = update_dists(scene->d, st))) { hipFree(dirDev); hipFree(cubeDev); return rc; }     /* AmbCube_Bake -> Pt_RayGen -> PtScene_Update, pt.c:2625 */
+        if ((rc = scene_update_dists_all(scene))) { hipFree(dirDev); hipFree(cubeDev); return rc; }     /* AmbCube_Bake -> Pt_RayGen -> PtScene_Update, pt.c:2625 */
         k_init_rays<<<(samples + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], nullptr, nullptr,
             f4_v(origin[0], origin[1], origin[2], origin[3]), dirDev, samples, sampleIndex, seed, 0);
         rc = integrate_paths(scene, samples, maxBounces, nullptr, nullptr);

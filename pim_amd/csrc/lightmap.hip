@@ -16,6 +16,8 @@
 #include "pt_host.h"
 #include "pt_api.h"
 #include "pt_scene_fn.h"
+#include <cstring>
+#include <algorithm>
 
 namespace pt {
 
@@ -34,7 +36,10 @@ struct BakeArgs
     int32_t* activeCount;
     uint4* bakeRng;              /* per slot: the bake stream */
     float4* bakeRd;              /* per slot: direction of the current sample */
+    int32_t tileFirst, tileStep; /* multi-device: this context bakes the 64x64-texel tiles t with t % tileStep == tileFirst (1 step: all) */
 };
+
+static constexpr int32_t kBakeTile = 64;     /* SURVEY 8e / BASELINE config 4: 64x64-texel tiles round-robin over the devices */
 
 /* kGiAxii, rendering/lightmap.h:14-21 */
 __device__ __forceinline__ v4 gi_axis(int i)
@@ -74,7 +79,15 @@ __global__ __launch_bounds__(256) void k_bake_begin(BakeArgs b, PathState ps)
         iWork = b.workBegin + w;
         const TexelRef t = texel_ref(b, iWork);
         const int32_t iLightmap = (int32_t)(iWork / t.lmLen);
-        if (t.sampleCounts[t.iTexel] != 0.0f)
+        bool mine = true;
+        if (b.tileStep > 1)
+        {
+            const int32_t perRow = (b.lmSize + kBakeTile - 1) / kBakeTile;
+            const int32_t tx = (t.iTexel % b.lmSize) / kBakeTile, ty = (t.iTexel / b.lmSize) / kBakeTile;
+            const int64_t tile = ((int64_t)iLightmap * perRow + ty) * perRow + tx;
+            mine = (int32_t)(tile % b.tileStep) == b.tileFirst;
+        }
+        if (mine && t.sampleCounts[t.iTexel] != 0.0f)
         {
             rng = pcg4((uint32_t)t.iTexel, (uint32_t)iLightmap, b.passIndex, b.seed ^ PT_TAG_BAKE);
             prng = pcg4((uint32_t)t.iTexel, (uint32_t)iLightmap, b.passIndex, b.seed ^ PT_TAG_BAKE_PT);
@@ -180,20 +193,16 @@ __global__ __launch_bounds__(256) void k_bake_accumulate(BakeArgs b, const PimRe
 
 using namespace pt;
 
-extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCount, int32_t lmSize, float texelsPerMeter,
-    float timeSlice, int32_t spp, uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd)
+/* one context bakes its tiles of the work items [texelBegin, texelEnd).  outPages == pages: results go straight to the caller's
+ * pages; else (a peer context) into outPages, page blocks of probes | sampleCounts only, from which the caller merges this
+ * context's tiles. */
+static int lightmap_bake_one(PimScene* scene, PimLightmapPage* pages, int32_t lmSize, float texelsPerMeter,
+    float timeSlice, int32_t spp, uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd,
+    int32_t tileFirst, int32_t tileStep, float* const* outProbes, float* const* outCounts)
 {
-    int rc = check_ready(); if (rc) return rc;
-    if (!scene || lmCount < 0 || lmSize <= 0 || (lmCount > 0 && !pages) || !(texelsPerMeter > 0.0f))
-    { set_error("lightmap_bake: bad argument"); return PIMGPU_E_INVALID; }
+    int rc = PIMGPU_OK;
     const int64_t lmLen = (int64_t)lmSize * lmSize;
-    const int64_t total = (int64_t)lmCount * lmLen;
-    if (texelBegin < 0) texelBegin = 0;
-    if (texelEnd < 0 || texelEnd > total) texelEnd = total;
     hipStream_t st = g_lib.stream;
-    if ((rc = update_dists(scene->d, st))) return rc;               /* PtScene_Update, lm.c:1209 */
-    if (texelEnd <= texelBegin) { PT_HIP(hipStreamSynchronize(st)); return PIMGPU_OK; }
-    if (spp < 1) spp = 1;
 
     const int32_t pageBase = (int32_t)(texelBegin / lmLen);
     const int32_t pageLast = (int32_t)((texelEnd - 1) / lmLen);
@@ -226,6 +235,7 @@ extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int
         b.workCount = (int32_t)std::min<int64_t>(kChunk, texelEnd - begin);
         b.metersPerTexel = 1.0f / texelsPerMeter; b.timeSlice = timeSlice; b.passIndex = passIndex; b.seed = seed;
         b.activeList = activeList; b.activeCount = activeCount; b.bakeRng = bakeRng; b.bakeRd = bakeRd;
+        b.tileFirst = tileFirst; b.tileStep = tileStep;
         hipMemsetAsync(activeCount, 0, 4, st);
         k_bake_begin<<<(b.workCount + 255) / 256, 256, 0, st>>>(b, w.ps);
         int32_t nActive = 0;
@@ -245,11 +255,75 @@ extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int
         for (int32_t i = 0; i < pageCount; ++i)
         {
             float* host = pages[pageBase + i].block; float* dev = devPages[(size_t)i];
-            hipMemcpyAsync(host, dev, sizeof(float) * (size_t)lmLen * 20, hipMemcpyDeviceToHost, st);
-            hipMemcpyAsync(host + (size_t)lmLen * 26, dev + (size_t)lmLen * 26, sizeof(float) * (size_t)lmLen, hipMemcpyDeviceToHost, st);
+            float* hostProbes = outProbes ? outProbes[pageBase + i] : host;
+            float* hostCounts = outCounts ? outCounts[pageBase + i] : host + (size_t)lmLen * 26;
+            hipMemcpyAsync(hostProbes, dev, sizeof(float) * (size_t)lmLen * 20, hipMemcpyDeviceToHost, st);
+            hipMemcpyAsync(hostCounts, dev + (size_t)lmLen * 26, sizeof(float) * (size_t)lmLen, hipMemcpyDeviceToHost, st);
         }
         if (hipStreamSynchronize(st) != hipSuccess) { set_error("lightmap_bake: device error"); rc = PIMGPU_E_DEVICE; }
     }
     cleanup();
+    return rc;
+}
+
+extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCount, int32_t lmSize, float texelsPerMeter,
+    float timeSlice, int32_t spp, uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || lmCount < 0 || lmSize <= 0 || (lmCount > 0 && !pages) || !(texelsPerMeter > 0.0f))
+    { set_error("lightmap_bake: bad argument"); return PIMGPU_E_INVALID; }
+    const int64_t lmLen = (int64_t)lmSize * lmSize;
+    const int64_t total = (int64_t)lmCount * lmLen;
+    if (texelBegin < 0) texelBegin = 0;
+    if (texelEnd < 0 || texelEnd > total) texelEnd = total;
+    if ((rc = scene_update_dists_all(scene))) return rc;            /* PtScene_Update, lm.c:1209 */
+    if (texelEnd <= texelBegin) { PT_HIP(hipStreamSynchronize(g_lib.stream)); return PIMGPU_OK; }
+    if (spp < 1) spp = 1;
+    const int G = g_libCount;
+    if (G <= 1 || !scene->peers[1])
+        return lightmap_bake_one(scene, pages, lmSize, texelsPerMeter, timeSlice, spp, passIndex, seed, maxBounces, texelBegin, texelEnd, 0, 1, nullptr, nullptr);
+    /*
+     * Several devices: 64x64-texel tiles round-robin, each texel's samples in order on ONE device (SG_Accumulate is
+     * order dependent, sphgauss.c:19-58).  Disjoint writes, no reduction: context 0 writes the caller's pages, the others write
+     * staging copies of probes | sampleCounts from which their tiles are copied in.  A texel's result depends on its own
+     * streams and the scene only, so the pages equal the one-device bake bit for bit.
+     */
+    const int32_t pageBase = (int32_t)(texelBegin / lmLen), pageLast = (int32_t)((texelEnd - 1) / lmLen);
+    std::vector<std::vector<float*>> probes((size_t)G, std::vector<float*>((size_t)lmCount, nullptr)), counts((size_t)G, std::vector<float*>((size_t)lmCount, nullptr));
+    bool okAlloc = true;
+    for (int i = 1; i < G && okAlloc; ++i)
+        for (int32_t pg = pageBase; pg <= pageLast && okAlloc; ++pg)
+        {
+            probes[(size_t)i][(size_t)pg] = (float*)pimgpu_host_alloc(sizeof(float) * (size_t)lmLen * 20);
+            counts[(size_t)i][(size_t)pg] = (float*)pimgpu_host_alloc(sizeof(float) * (size_t)lmLen);
+            okAlloc = probes[(size_t)i][(size_t)pg] && counts[(size_t)i][(size_t)pg];
+        }
+    if (okAlloc)
+        rc = for_each_context(G, [&](int i) {
+            return lightmap_bake_one(i == 0 ? scene : scene->peers[i], pages, lmSize, texelsPerMeter, timeSlice, spp, passIndex, seed, maxBounces,
+                texelBegin, texelEnd, i, G, i == 0 ? nullptr : probes[(size_t)i].data(), i == 0 ? nullptr : counts[(size_t)i].data());
+        });
+    else { set_error("lightmap_bake: out of page-locked host memory"); rc = PIMGPU_E_NOMEM; }
+    if (!rc)
+    {
+        const int32_t perRow = (lmSize + kBakeTile - 1) / kBakeTile;
+        for (int32_t pg = pageBase; pg <= pageLast; ++pg)
+            for (int32_t ty = 0; ty < perRow; ++ty)
+                for (int32_t tx = 0; tx < perRow; ++tx)
+                {
+                    const int owner = (int)((((int64_t)pg * perRow + ty) * perRow + tx) % G);
+                    if (owner == 0) continue;
+                    const int32_t x0 = tx * kBakeTile, x1 = std::min(lmSize, x0 + kBakeTile);
+                    for (int32_t y = ty * kBakeTile; y < std::min(lmSize, (ty + 1) * kBakeTile); ++y)
+                    {
+                        const size_t row = (size_t)y * lmSize;
+                        float* dst = pages[pg].block;
+                        for (int k = 0; k < 5; ++k)
+                            memcpy(dst + ((size_t)k * lmLen + row + x0) * 4, probes[(size_t)owner][(size_t)pg] + ((size_t)k * lmLen + row + x0) * 4, sizeof(float) * 4 * (size_t)(x1 - x0));
+                        memcpy(dst + (size_t)lmLen * 26 + row + x0, counts[(size_t)owner][(size_t)pg] + row + x0, sizeof(float) * (size_t)(x1 - x0));
+                    }
+                }
+    }
+    for (int i = 1; i < G; ++i) for (int32_t pg = 0; pg < lmCount; ++pg) { pimgpu_host_free(probes[(size_t)i][(size_t)pg]); pimgpu_host_free(counts[(size_t)i][(size_t)pg]); }
     return rc;
 }

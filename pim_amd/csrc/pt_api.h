@@ -7,6 +7,7 @@
 #include "pt_host.h"
 #include <vector>
 #include <utility>
+#include <functional>
 
 /* PtScene (rendering/path_tracer.c:122-166) resident in HBM */
 struct PimScene
@@ -27,6 +28,11 @@ struct PimScene
     float metersPerCell = 1.5f;
     float bvhBuildMs = 0.0f, setupMs = 0.0f;
     int32_t bvhDepth = 0;
+    /* multi-device (pimgpu_init_devices with more than one entry): this is the replica of context 0, peers[i] the one of
+     * context i (peers[0] unused); liveBase = the light histograms as they were after the last UpdateDists, on context 0,
+     * against which every replica's own increments are measured when the histograms are summed (api.hip, scene_update_dists_all) */
+    PimScene* peers[16] = {};
+    uint32_t* liveBase = nullptr; uint32_t* liveTmp = nullptr;
 };
 
 /* PtTrace (rendering/path_tracer.h:44-52): running-mean float3 images in HBM */
@@ -35,6 +41,8 @@ struct PimTrace
     int32_t width = 0, height = 0;
     float* color = nullptr; float* albedo = nullptr; float* normal = nullptr;
     PimTraceStats stats = {};
+    PimTrace* peers[16] = {};            /* multi-device: context i keeps rows [H*i/G, H*(i+1)/G) of ITS copy up to date */
+    bool gathered = true;                /* multi-device: the copy of context 0 holds every band (stddev / buffers gather on demand) */
 };
 
 namespace pt {
@@ -110,9 +118,33 @@ struct Library
     int ensure_group(int g);
     void release_groups();
 };
-extern Library g_lib;
+/*
+ * One Library per entry of the device list of pimgpu_init_devices (a HIP device may appear more than once: two contexts on
+ * one GPU, which is how the one-GPU test box exercises the multi-device paths).  Every call runs against the CURRENT
+ * context of its host thread -- context 0 unless a DeviceScope says otherwise -- and the code below the entry points
+ * reaches it through the name it always used, g_lib.
+ */
+static constexpr int kMaxDevices = 16;
+extern Library g_libs[kMaxDevices];
+extern int g_libCount;                       /* contexts initialised by pimgpu_init_devices */
+Library& cur_lib();
+void set_cur_lib(Library* lib);
+#define g_lib (pt::cur_lib())
+struct DeviceScope
+{
+    Library* prev;
+    explicit DeviceScope(int index) : prev(&cur_lib()) { set_cur_lib(&g_libs[index]); hipSetDevice(g_libs[index].device); }
+    ~DeviceScope() { set_cur_lib(prev); hipSetDevice(prev->device); }
+};
 
 int check_ready();
+
+/* api.hip: UpdateDists on every replica, after summing the replicas' light-histogram increments (one replica: just UpdateDists) */
+int scene_update_dists_all(PimScene* scene);
+/* the rows of an image context i of G renders */
+inline void band_of(int32_t height, int i, int G, int32_t* rowBegin, int32_t* rowEnd) { *rowBegin = (int32_t)((int64_t)height * i / G); *rowEnd = (int32_t)((int64_t)height * (i + 1) / G); }
+/* run fn(i) for i in [0, count) on one host thread per context, each inside its DeviceScope; returns the first failure and keeps its message */
+int for_each_context(int count, const std::function<int(int)>& fn);
 
 /* setup.hip */
 int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float* pdfsDev, hipStream_t stream);

@@ -73,6 +73,21 @@ void PtSys_SetSceneProvider(PtSceneProviderFn fn, void* user) { ms_provider = fn
 
 void PtSys_Init(void)
 {
+    /* the reference fans out over every hardware thread of the machine (task.c:213-223); PIM_GPU_DEVICES = "0,1,2,..." fans
+     * out over those GPUs (pimgpu_init_devices), PIM_GPU_DEVICE / PtSysConfig.device pick one */
+    const char* list = ms_config.device < 0 ? getenv("PIM_GPU_DEVICES") : NULL;
+    if (list && *list)
+    {
+        int devices[16], n = 0;
+        for (const char* p = list; *p && n < 16; )
+        {
+            devices[n++] = atoi(p);
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        ms_ok = ok(pimgpu_init_devices(devices, n), "PtSys_Init");
+        return;
+    }
     int device = ms_config.device;
     if (device < 0) { const char* dev = getenv("PIM_GPU_DEVICE"); device = dev ? atoi(dev) : 0; }
     ms_ok = ok(pimgpu_init(device), "PtSys_Init");

@@ -1,0 +1,85 @@
+"""Run by tests/test_gpu_multi_device.py in a process of its own (the library keeps ONE device list per process):
+pimgpu_init_devices with a list of N entries -- all device 0 on the one-GPU test box: N contexts, streams, scene replicas and
+image copies on one GPU, which exercises every multi-device path except the physical peer copies -- against the oracle, bit for bit.
+
+    python -m tests.multi_device_worker <N>"""
+import sys
+
+import numpy as np
+
+from pim_amd import api, scenes
+from tests.gpu_util import assert_bits_equal
+from tests.util import OracleScene
+
+
+def main(n):
+    api.init_devices([0] * n)
+    lib = api.load_library()
+    assert lib.pimgpu_device_count() == n
+    sc = scenes.textured_cornell()
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("vertToEmit", "emitToVert", "cellLength", "pdf", "cdf", "live"):
+        assert_bits_equal(gl[k], ol[k], k)
+
+    # image: bands of rows, one per context; 50 rows do not divide by 3
+    W, H = 96, 50
+    t = api.Trace(W, H)
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    cam = scenes.pt_test_camera()
+    dg, do = scenes.default_dof(), scenes.default_dof()
+    for s in range(4):
+        p = scenes.trace_params(s, seed=17, max_bounces=5)
+        t.trace(g, cam, dg, p)
+        so = o.trace_image(img, W, H, cam, do, p)
+        sg = t.stats()
+        assert (sg.extensionRays, sg.shadowRays, sg.otherRays, sg.paths) == (so.extensionRays, so.shadowRays, so.otherRays, so.paths), f"frame {s}"
+        assert dg.focalLength == do.focalLength
+    color, albedo, normal = t.download()
+    assert_bits_equal(color, img[0], "color"); assert_bits_equal(albedo, img[1], "albedo"); assert_bits_equal(normal, img[2], "normal")
+    assert t.stddev() == o.stddev(img[0], W, H)                    # gathers the bands on context 0
+    assert t.stddev_noalloc() == t.stddev()
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("live", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k + " after 4 frames")      # the replicas' histograms were summed before every UpdateDists
+    assert (gl["live"] > 0).any()
+
+    # the entry points that run on the first device see (and feed) the same histograms
+    origin = np.array([0.5, -1.0, 0.25, 0.0], np.float32)
+    cg, dgn = g.raygen(origin, 20000, sampleIndex=1, seed=3, maxBounces=4)
+    co, don = o.raygen(origin, 20000, sampleIndex=1, seed=3, maxBounces=4)
+    assert_bits_equal(cg, co, "raygen colors")
+    t.trace(g, cam, dg, scenes.trace_params(4, seed=17, max_bounces=5)); o.trace_image(img, W, H, cam, do, scenes.trace_params(4, seed=17, max_bounces=5))
+    assert_bits_equal(t.download()[0], img[0], "color after raygen")
+
+    # lightmap bake: 64x64 tiles round-robin over the contexts; 96^2 pages = 2x2 tiles with a ragged edge
+    S = 96
+    pages = scenes.lightmap_pages_for(sc, S, 3.0, max_pages=2)
+    pg = [p.copy() for p in pages]; po = [p.copy() for p in pages]
+    for passIndex, (slice_, spp) in enumerate([(1.0, 2), (0.6, 2)]):
+        g.lightmap_bake(pg, S, 3.0, slice_, spp, passIndex=passIndex, seed=5, maxBounces=4)
+        o.lightmap_bake(po, S, 3.0, slice_, spp, passIndex=passIndex, seed=5, maxBounces=4)
+        for a, b in zip(pg, po):
+            assert_bits_equal(a, b, f"page after pass {passIndex}")
+    begin, end = S * S // 3, S * S + 1000                           # a sub-range across the page boundary
+    g.lightmap_bake(pg, S, 3.0, 1.0, 1, passIndex=9, seed=5, maxBounces=4, texelBegin=begin, texelEnd=end)
+    o.lightmap_bake(po, S, 3.0, 1.0, 1, passIndex=9, seed=5, maxBounces=4, texelBegin=begin, texelEnd=end)
+    for a, b in zip(pg, po):
+        assert_bits_equal(a, b, "sub-range pages")
+
+    g.rebuild_bvh()
+    ro, rd = scenes.random_rays(sc, 5000, seed=2)
+    assert g.intersect(ro, rd).tobytes() == o.intersect(ro, rd).tobytes()
+    t.close(); g.close()
+    api.shutdown()
+    # a second list in the same process after shutdown
+    api.init_devices([0])
+    sc2 = scenes.cornell_box()
+    g = api.Scene(sc2.desc); g.close()
+    api.shutdown()
+    print(f"MULTI-DEVICE OK {n}")
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]))

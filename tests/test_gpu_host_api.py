@@ -59,7 +59,8 @@ def write_scene_file(path, sc, cam):
         f.write(sc.lut.tobytes())
 
 
-def test_reference_caller_gets_the_oracles_bits(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_reference_caller_gets_the_oracles_bits(tmp_path, devices):
     exe = os.path.join(ROOT, "pim_amd", "host", "build", "ref_caller")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "pim_amd", "host")])
@@ -67,7 +68,10 @@ def test_reference_caller_gets_the_oracles_bits(tmp_path):
     cam = scenes.pt_test_camera()
     scene_path, out_path = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
     write_scene_file(scene_path, sc, cam)
-    run = subprocess.run([exe, scene_path, out_path], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ)
+    if devices:
+        env["PIM_GPU_DEVICES"] = devices            # the same caller fanned out over two contexts: same bits
+    run = subprocess.run([exe, scene_path, out_path], capture_output=True, text=True, timeout=120, env=env)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "ref_caller ok" in run.stdout and "Vertex Count: 324" in run.stdout and "Emissive Count: 12" in run.stdout      # PtScene_Gui
     assert "Blade Count: 5" in run.stdout                                                                                # DofInfo_Gui
