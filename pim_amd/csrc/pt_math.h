@@ -727,11 +727,15 @@ PT_FN Bilinear BilinearWrap(int32_t sx, int32_t sy, v2 uv)                      
 }
 PT_FN v4 UvBilinearWrap_c32(const uint32_t* tex, int32_t sx, int32_t sy, v2 uv)                 /* :375-379, :240-249 */
 {
+    /* a flat texture (GenFlatTexture's 1x1, render_system.c:1119-1134: every material of the Cornell scenes): the four taps are
+     * the one texel and lerp(a, a, t) = a + (a - a) * t = a exactly, so one fetch and one decode give the same bits */
+    if ((sx | sy) == 1) return GammaDecode_rgba8(tex[0]);
     Bilinear bi = BilinearWrap(sx, sy, uv);
     return f4_bilerp(GammaDecode_rgba8(tex[bi.a]), GammaDecode_rgba8(tex[bi.b]), GammaDecode_rgba8(tex[bi.c]), GammaDecode_rgba8(tex[bi.d]), bi.frac);
 }
 PT_FN v4 UvBilinearWrap_xy16(const uint32_t* tex, int32_t sx, int32_t sy, v2 uv)                /* :388-392, :250-260 */
 {
+    if ((sx | sy) == 1) return f4_normalize3(Xy16ToNormalTs(tex[0]));          /* flat: as above */
     Bilinear bi = BilinearWrap(sx, sy, uv);
     v4 r = f4_bilerp(Xy16ToNormalTs(tex[bi.a]), Xy16ToNormalTs(tex[bi.b]), Xy16ToNormalTs(tex[bi.c]), Xy16ToNormalTs(tex[bi.d]), bi.frac);
     return f4_normalize3(r);

@@ -45,8 +45,11 @@ static constexpr int kTraceBlocksPerCU = 8;
 #define PT_TRI_VOTE 16
 #endif
 
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 1      /* waves per SIMD the kernel is compiled for at least (1: whatever its registers give, 6 at 73 VGPRs) */
+#endif
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kTraceThreads) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
+__global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
     unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work,
     uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk, int32_t stackCap)
