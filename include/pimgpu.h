@@ -388,6 +388,20 @@ int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCoun
     uint32_t passIndex, uint32_t seed, int32_t maxBounces,
     int64_t texelBegin, int64_t texelEnd);
 
+/* The same bake on pages that STAY in HBM between calls.  The reference bakes in place in host memory, spp samples per
+ * frame (render_system.c:196-198), and reads the pages only when it uploads them to the renderer (every 10 s, :200-210)
+ * or saves them (lightmap.c:1225): a caller in that position creates a set, uploads its pages once (after
+ * EmbedAttributes or LmPack_Load), bakes as often as it likes with no PCIe traffic at all, and downloads probes |
+ * sampleCounts -- the parts BakeFn writes (lightmap.c:1194-1200) -- when it needs them.  Same kernels, same bits as
+ * pimgpu_lightmap_bake.  With a device list every context keeps a replica and bakes its 64x64 tiles of it. */
+typedef struct PimLightmapSet PimLightmapSet;
+int pimgpu_lightmap_set_create(int32_t lmCount, int32_t lmSize, PimLightmapSet** out);      /* zeroed pages */
+int pimgpu_lightmap_set_destroy(PimLightmapSet* set);
+int pimgpu_lightmap_set_upload(PimLightmapSet* set, const PimLightmapPage* pages);          /* whole pages, host -> HBM */
+int pimgpu_lightmap_set_download(const PimLightmapSet* set, PimLightmapPage* pages);        /* probes | sampleCounts, HBM -> host */
+int pimgpu_lightmap_set_bake(PimScene* scene, PimLightmapSet* set, float texelsPerMeter, float timeSlice, int32_t spp,
+    uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd);
+
 /* chartnode_t (lightmap.c:48-55), field for field at the same offsets: 64 bytes (the reference's float4 is 16-aligned) */
 typedef struct PimChartNode
 {

@@ -118,6 +118,7 @@ EXPORTS = [
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc", "pimgpu_init_devices", "pimgpu_device_count",
+    "pimgpu_lightmap_set_create", "pimgpu_lightmap_set_destroy", "pimgpu_lightmap_set_upload", "pimgpu_lightmap_set_download", "pimgpu_lightmap_set_bake",
 ]
 
 _LIB = None
@@ -250,6 +251,48 @@ class Scene:
         check(self.lib.pimgpu_lightmap_bake(self.handle, arr, C.c_int32(len(pages)), C.c_int32(lmSize), C.c_float(texelsPerMeter),
               C.c_float(timeSlice), C.c_int32(spp), C.c_uint32(passIndex), C.c_uint32(seed), C.c_int32(maxBounces),
               C.c_int64(texelBegin), C.c_int64(texelEnd)), "pimgpu_lightmap_bake")
+
+
+def _page_table(pages, lmSize):
+    arr = (PimLightmapPage * len(pages))()
+    for i, p in enumerate(pages):
+        assert p.dtype == np.float32 and p.flags["C_CONTIGUOUS"] and p.size == lmSize * lmSize * 27
+        arr[i].block = p.ctypes.data
+    return arr
+
+
+class LightmapSet:
+    """lightmap pages that stay in HBM between bake calls (pimgpu_lightmap_set_*): upload once, bake many times, download
+    probes | sampleCounts when the host wants them"""
+
+    def __init__(self, lmCount, lmSize):
+        self.lib = load_library()
+        self.lmCount, self.lmSize = lmCount, lmSize
+        self.handle = C.c_void_p()
+        check(self.lib.pimgpu_lightmap_set_create(C.c_int32(lmCount), C.c_int32(lmSize), C.byref(self.handle)), "pimgpu_lightmap_set_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.pimgpu_lightmap_set_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, pages):
+        assert len(pages) == self.lmCount
+        check(self.lib.pimgpu_lightmap_set_upload(self.handle, _page_table(pages, self.lmSize)), "pimgpu_lightmap_set_upload")
+
+    def download(self, pages):
+        assert len(pages) == self.lmCount
+        check(self.lib.pimgpu_lightmap_set_download(self.handle, _page_table(pages, self.lmSize)), "pimgpu_lightmap_set_download")
+
+    def bake(self, scene, texelsPerMeter, timeSlice, spp, passIndex=0, seed=0, maxBounces=0, texelBegin=0, texelEnd=-1):
+        check(self.lib.pimgpu_lightmap_set_bake(scene.handle, self.handle, C.c_float(texelsPerMeter), C.c_float(timeSlice), C.c_int32(spp),
+              C.c_uint32(passIndex), C.c_uint32(seed), C.c_int32(maxBounces), C.c_int64(texelBegin), C.c_int64(texelEnd)), "pimgpu_lightmap_set_bake")
 
 
 class Trace:

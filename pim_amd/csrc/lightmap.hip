@@ -193,12 +193,21 @@ __global__ __launch_bounds__(256) void k_bake_accumulate(BakeArgs b, const PimRe
 
 using namespace pt;
 
+/* pages that stay in HBM between calls (pimgpu_lightmap_set_*): one block per page in the reference's layout; with several
+ * contexts every context holds a replica and keeps ITS tiles of it up to date */
+struct PimLightmapSet
+{
+    int32_t lmCount = 0, lmSize = 0;
+    std::vector<float*> dev;
+    PimLightmapSet* peers[kMaxDevices] = {};
+};
+
 /* one context bakes its tiles of the work items [texelBegin, texelEnd).  outPages == pages: results go straight to the caller's
  * pages; else (a peer context) into outPages, page blocks of probes | sampleCounts only, from which the caller merges this
  * context's tiles. */
 static int lightmap_bake_one(PimScene* scene, PimLightmapPage* pages, int32_t lmSize, float texelsPerMeter,
     float timeSlice, int32_t spp, uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd,
-    int32_t tileFirst, int32_t tileStep, float* const* outProbes, float* const* outCounts)
+    int32_t tileFirst, int32_t tileStep, float* const* outProbes, float* const* outCounts, float* const* resident = nullptr)
 {
     int rc = PIMGPU_OK;
     const int64_t lmLen = (int64_t)lmSize * lmSize;
@@ -210,10 +219,12 @@ static int lightmap_bake_one(PimScene* scene, PimLightmapPage* pages, int32_t lm
     const size_t pageFloats = (size_t)lmLen * (5 * 4 + 3 + 3 + 1);
     std::vector<float*> devPages((size_t)pageCount, nullptr);
     float** devPageTable = nullptr; int64_t* activeList = nullptr; int32_t* activeCount = nullptr; uint4* bakeRng = nullptr; float4* bakeRd = nullptr;
-    auto cleanup = [&]() { for (float* p : devPages) hipFree(p); hipFree(devPageTable); hipFree(activeList); hipFree(activeCount); hipFree(bakeRng); hipFree(bakeRd); };
+    /* resident != nullptr: the pages already live in HBM (a PimLightmapSet, indexed by page): nothing is copied in or out */
+    auto cleanup = [&]() { if (!resident) for (float* p : devPages) hipFree(p); hipFree(devPageTable); hipFree(activeList); hipFree(activeCount); hipFree(bakeRng); hipFree(bakeRd); };
     auto oom = [&]() { cleanup(); set_error("lightmap_bake: out of device memory"); return PIMGPU_E_NOMEM; };
     for (int32_t i = 0; i < pageCount; ++i)
     {
+        if (resident) { devPages[(size_t)i] = resident[pageBase + i]; continue; }
         if (!pages[pageBase + i].block) { cleanup(); set_error("lightmap_bake: page %d has no block", pageBase + i); return PIMGPU_E_INVALID; }
         if (hipMalloc(&devPages[(size_t)i], sizeof(float) * pageFloats) != hipSuccess) return oom();
         hipMemcpyAsync(devPages[(size_t)i], pages[pageBase + i].block, sizeof(float) * pageFloats, hipMemcpyHostToDevice, st);
@@ -249,7 +260,8 @@ static int lightmap_bake_one(PimScene* scene, PimLightmapPage* pages, int32_t lm
             if (!rc) k_bake_accumulate<<<(nActive + 255) / 256, 256, 0, st>>>(b, w.results, nActive);
         }
     }
-    if (!rc)
+    if (!rc && resident) { if (hipStreamSynchronize(st) != hipSuccess) { set_error("lightmap_bake: device error"); rc = PIMGPU_E_DEVICE; } }
+    else if (!rc)
     {
         /* probes and sampleCounts are the only parts BakeFn writes (lm.c:1194-1200) */
         for (int32_t i = 0; i < pageCount; ++i)
@@ -265,6 +277,8 @@ static int lightmap_bake_one(PimScene* scene, PimLightmapPage* pages, int32_t lm
     cleanup();
     return rc;
 }
+
+static void merge_tiles(float* dstPage, const float* srcProbes, const float* srcCounts, int32_t pg, int32_t lmSize, int owner, int G);
 
 extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int32_t lmCount, int32_t lmSize, float texelsPerMeter,
     float timeSlice, int32_t spp, uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd)
@@ -306,24 +320,148 @@ extern "C" int pimgpu_lightmap_bake(PimScene* scene, PimLightmapPage* pages, int
     else { set_error("lightmap_bake: out of page-locked host memory"); rc = PIMGPU_E_NOMEM; }
     if (!rc)
     {
-        const int32_t perRow = (lmSize + kBakeTile - 1) / kBakeTile;
         for (int32_t pg = pageBase; pg <= pageLast; ++pg)
-            for (int32_t ty = 0; ty < perRow; ++ty)
-                for (int32_t tx = 0; tx < perRow; ++tx)
-                {
-                    const int owner = (int)((((int64_t)pg * perRow + ty) * perRow + tx) % G);
-                    if (owner == 0) continue;
-                    const int32_t x0 = tx * kBakeTile, x1 = std::min(lmSize, x0 + kBakeTile);
-                    for (int32_t y = ty * kBakeTile; y < std::min(lmSize, (ty + 1) * kBakeTile); ++y)
-                    {
-                        const size_t row = (size_t)y * lmSize;
-                        float* dst = pages[pg].block;
-                        for (int k = 0; k < 5; ++k)
-                            memcpy(dst + ((size_t)k * lmLen + row + x0) * 4, probes[(size_t)owner][(size_t)pg] + ((size_t)k * lmLen + row + x0) * 4, sizeof(float) * 4 * (size_t)(x1 - x0));
-                        memcpy(dst + (size_t)lmLen * 26 + row + x0, counts[(size_t)owner][(size_t)pg] + row + x0, sizeof(float) * (size_t)(x1 - x0));
-                    }
-                }
+            for (int owner = 1; owner < G; ++owner)
+                merge_tiles(pages[pg].block, probes[(size_t)owner][(size_t)pg], counts[(size_t)owner][(size_t)pg], pg, lmSize, owner, G);
     }
     for (int i = 1; i < G; ++i) for (int32_t pg = 0; pg < lmCount; ++pg) { pimgpu_host_free(probes[(size_t)i][(size_t)pg]); pimgpu_host_free(counts[(size_t)i][(size_t)pg]); }
     return rc;
+}
+
+
+/* multi-device: the tiles of context `owner` (64x64 texels, round-robin over G) of page pg, from that context's probes | sampleCounts
+ * into the caller's page */
+static void merge_tiles(float* dstPage, const float* srcProbes, const float* srcCounts, int32_t pg, int32_t lmSize, int owner, int G)
+{
+    const int64_t lmLen = (int64_t)lmSize * lmSize;
+    const int32_t perRow = (lmSize + kBakeTile - 1) / kBakeTile;
+    for (int32_t ty = 0; ty < perRow; ++ty)
+        for (int32_t tx = 0; tx < perRow; ++tx)
+        {
+            if ((int)((((int64_t)pg * perRow + ty) * perRow + tx) % G) != owner) continue;
+            const int32_t x0 = tx * kBakeTile, x1 = std::min(lmSize, x0 + kBakeTile);
+            for (int32_t y = ty * kBakeTile; y < std::min(lmSize, (ty + 1) * kBakeTile); ++y)
+            {
+                const size_t row = (size_t)y * lmSize;
+                for (int k = 0; k < 5; ++k)
+                    memcpy(dstPage + ((size_t)k * lmLen + row + x0) * 4, srcProbes + ((size_t)k * lmLen + row + x0) * 4, sizeof(float) * 4 * (size_t)(x1 - x0));
+                memcpy(dstPage + (size_t)lmLen * 26 + row + x0, srcCounts + row + x0, sizeof(float) * (size_t)(x1 - x0));
+            }
+        }
+}
+
+static thread_local bool g_makingSetPeer = false;
+
+extern "C" int pimgpu_lightmap_set_destroy(PimLightmapSet* set)
+{
+    if (!set) return PIMGPU_OK;
+    for (int i = 1; i < kMaxDevices; ++i)
+        if (set->peers[i])
+        {
+            PimLightmapSet* peer = set->peers[i]; set->peers[i] = nullptr;
+            if (i < g_libCount) { DeviceScope scope(i); pimgpu_lightmap_set_destroy(peer); }
+        }
+    if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
+    for (float* p : set->dev) hipFree(p);
+    delete set;
+    return PIMGPU_OK;
+}
+
+extern "C" int pimgpu_lightmap_set_create(int32_t lmCount, int32_t lmSize, PimLightmapSet** out)
+{
+    if (out) *out = nullptr;
+    int rc = check_ready(); if (rc) return rc;
+    if (!out || lmCount <= 0 || lmSize <= 0 || lmSize > 16384) { set_error("lightmap_set_create: bad argument"); return PIMGPU_E_INVALID; }
+    PimLightmapSet* set = new PimLightmapSet();
+    set->lmCount = lmCount; set->lmSize = lmSize;
+    const size_t bytes = sizeof(float) * 27 * (size_t)lmSize * lmSize;
+    set->dev.assign((size_t)lmCount, nullptr);
+    for (int32_t i = 0; i < lmCount; ++i)
+    {
+        if (hipMalloc(&set->dev[(size_t)i], bytes) != hipSuccess) { pimgpu_lightmap_set_destroy(set); set_error("lightmap_set_create: out of device memory"); return PIMGPU_E_NOMEM; }
+        hipMemsetAsync(set->dev[(size_t)i], 0, bytes, g_lib.stream);
+    }
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    if (g_libCount > 1 && !g_makingSetPeer)
+    {
+        rc = for_each_context(g_libCount, [&](int i) {
+            if (i == 0) return PIMGPU_OK;
+            g_makingSetPeer = true;
+            const int r = pimgpu_lightmap_set_create(lmCount, lmSize, &set->peers[i]);
+            g_makingSetPeer = false;
+            return r;
+        });
+        if (rc) { pimgpu_lightmap_set_destroy(set); return rc; }
+    }
+    *out = set;
+    return PIMGPU_OK;
+}
+
+extern "C" int pimgpu_lightmap_set_upload(PimLightmapSet* set, const PimLightmapPage* pages)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!set || !pages) { set_error("lightmap_set_upload: NULL argument"); return PIMGPU_E_INVALID; }
+    for (int32_t i = 0; i < set->lmCount; ++i) if (!pages[i].block) { set_error("lightmap_set_upload: page %d has no block", i); return PIMGPU_E_INVALID; }
+    const size_t bytes = sizeof(float) * 27 * (size_t)set->lmSize * set->lmSize;
+    const int G = (g_libCount > 1 && set->peers[1]) ? g_libCount : 1;
+    return for_each_context(G, [&](int c) {
+        PimLightmapSet* s = c == 0 ? set : set->peers[c];
+        for (int32_t i = 0; i < s->lmCount; ++i) PT_HIP(hipMemcpyAsync(s->dev[(size_t)i], pages[i].block, bytes, hipMemcpyHostToDevice, g_lib.stream));
+        PT_HIP(hipStreamSynchronize(g_lib.stream));
+        return PIMGPU_OK;
+    });
+}
+
+extern "C" int pimgpu_lightmap_set_download(const PimLightmapSet* set, PimLightmapPage* pages)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!set || !pages) { set_error("lightmap_set_download: NULL argument"); return PIMGPU_E_INVALID; }
+    for (int32_t i = 0; i < set->lmCount; ++i) if (!pages[i].block) { set_error("lightmap_set_download: page %d has no block", i); return PIMGPU_E_INVALID; }
+    const size_t lmLen = (size_t)set->lmSize * set->lmSize;
+    /* probes and sampleCounts: the parts BakeFn writes (lm.c:1194-1200); position / normal are the caller's own */
+    for (int32_t i = 0; i < set->lmCount; ++i)
+    {
+        PT_HIP(hipMemcpyAsync(pages[i].block, set->dev[(size_t)i], sizeof(float) * lmLen * 20, hipMemcpyDeviceToHost, g_lib.stream));
+        PT_HIP(hipMemcpyAsync(pages[i].block + lmLen * 26, set->dev[(size_t)i] + lmLen * 26, sizeof(float) * lmLen, hipMemcpyDeviceToHost, g_lib.stream));
+    }
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    const int G = (g_libCount > 1 && set->peers[1]) ? g_libCount : 1;
+    if (G <= 1) return PIMGPU_OK;
+    /* the other contexts' tiles: one staging page at a time */
+    float* probes = (float*)pimgpu_host_alloc(sizeof(float) * lmLen * 20);
+    float* counts = (float*)pimgpu_host_alloc(sizeof(float) * lmLen);
+    if (!probes || !counts) { pimgpu_host_free(probes); pimgpu_host_free(counts); set_error("lightmap_set_download: out of page-locked host memory"); return PIMGPU_E_NOMEM; }
+    for (int c = 1; c < G && !rc; ++c)
+        for (int32_t i = 0; i < set->lmCount && !rc; ++i)
+        {
+            {
+                DeviceScope scope(c);
+                const float* dev = set->peers[c]->dev[(size_t)i];
+                if (hipMemcpyAsync(probes, dev, sizeof(float) * lmLen * 20, hipMemcpyDeviceToHost, g_lib.stream) != hipSuccess ||
+                    hipMemcpyAsync(counts, dev + lmLen * 26, sizeof(float) * lmLen, hipMemcpyDeviceToHost, g_lib.stream) != hipSuccess ||
+                    hipStreamSynchronize(g_lib.stream) != hipSuccess) { set_error("lightmap_set_download: device error"); rc = PIMGPU_E_DEVICE; }
+            }
+            if (!rc) merge_tiles(pages[i].block, probes, counts, i, set->lmSize, c, G);
+        }
+    pimgpu_host_free(probes); pimgpu_host_free(counts);
+    return rc;
+}
+
+extern "C" int pimgpu_lightmap_set_bake(PimScene* scene, PimLightmapSet* set, float texelsPerMeter, float timeSlice, int32_t spp,
+    uint32_t passIndex, uint32_t seed, int32_t maxBounces, int64_t texelBegin, int64_t texelEnd)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !set || !(texelsPerMeter > 0.0f)) { set_error("lightmap_set_bake: bad argument"); return PIMGPU_E_INVALID; }
+    const int64_t total = (int64_t)set->lmCount * set->lmSize * set->lmSize;
+    if (texelBegin < 0) texelBegin = 0;
+    if (texelEnd < 0 || texelEnd > total) texelEnd = total;
+    if ((rc = scene_update_dists_all(scene))) return rc;            /* PtScene_Update, lm.c:1209 */
+    if (texelEnd <= texelBegin) { PT_HIP(hipStreamSynchronize(g_lib.stream)); return PIMGPU_OK; }
+    if (spp < 1) spp = 1;
+    const int G = (g_libCount > 1 && scene->peers[1] && set->peers[1]) ? g_libCount : 1;
+    return for_each_context(G, [&](int c) {
+        PimLightmapSet* s = c == 0 ? set : set->peers[c];
+        return lightmap_bake_one(c == 0 ? scene : scene->peers[c], nullptr, s->lmSize, texelsPerMeter, timeSlice, spp, passIndex, seed, maxBounces,
+            texelBegin, texelEnd, c, G, nullptr, nullptr, s->dev.data());
+    });
 }

@@ -398,6 +398,7 @@ void Lightmap_New(Lightmap* lm, i32 size)
     lm->position = (float3*)(allocation + texelcount * 20);
     lm->normal = (float3*)(allocation + texelcount * 23);
     lm->sampleCounts = allocation + texelcount * 26;
+    Lightmap_Upload(lm);                                                 /* lightmap.c:122 */
 }
 
 void Lightmap_Del(Lightmap* lm)
@@ -407,9 +408,48 @@ void Lightmap_Del(Lightmap* lm)
 
 LmPack* LmPack_Get(void) { return &ms_pack; }
 
+/* ---- the pack's pages kept in HBM between LmPack_Bake calls (LmPack_SetResident) ---- */
+static i32 ms_lmMode;                        /* 0: every call copies the pages in and out (the reference's contract, default) */
+static PimLightmapSet* ms_lmSet;
+static i32 ms_lmSetCount, ms_lmSetSize;
+static const void* ms_lmSetKey;              /* probes[0] of page 0 when the set was filled */
+static bool ms_lmDeviceNewer;                /* mode 2: the device copy holds bake results the host pages do not have yet */
+
+static void lm_set_drop(void)
+{
+    if (ms_lmSet) pimgpu_lightmap_set_destroy(ms_lmSet);
+    ms_lmSet = NULL; ms_lmSetCount = ms_lmSetSize = 0; ms_lmSetKey = NULL; ms_lmDeviceNewer = false;
+}
+
+static PimLightmapPage* lm_page_table(const LmPack* pack)
+{
+    PimLightmapPage* pages = calloc((size_t)pack->lmCount, sizeof(PimLightmapPage));
+    if (pages) for (i32 i = 0; i < pack->lmCount; ++i) pages[i].block = &pack->lightmaps[i].probes[0]->x;   /* lightmap.c:95-110 */
+    return pages;
+}
+
+void LmPack_Sync(void)
+{
+    if (!ms_lmSet || !ms_lmDeviceNewer || ms_pack.lmCount != ms_lmSetCount || !ms_pack.lightmaps) return;
+    PimLightmapPage* pages = lm_page_table(&ms_pack);
+    if (!pages) return;
+    if (ok(pimgpu_lightmap_set_download(ms_lmSet, pages), "LmPack_Sync")) ms_lmDeviceNewer = false;
+    free(pages);
+}
+
+void LmPack_Invalidate(void) { LmPack_Sync(); lm_set_drop(); }
+
+void LmPack_SetResident(i32 mode)
+{
+    if (mode < 0 || mode > 2) mode = 0;
+    if (mode != ms_lmMode) LmPack_Invalidate();
+    ms_lmMode = mode;
+}
+
 void LmPack_Del(LmPack* pack)
 {
     if (!pack) return;
+    if (pack == &ms_pack) lm_set_drop();
     for (i32 i = 0; i < pack->lmCount; ++i) Lightmap_Del(pack->lightmaps + i);      /* lightmap.c:1104-1115 */
     free(pack->lightmaps);
     memset(pack, 0, sizeof(*pack));
@@ -421,6 +461,7 @@ void LmPack_EmbedAttributes(const PimDrawables* drawables, Lightmap* lightmaps, 
     PimLightmapPage* pages = calloc((size_t)lmCount, sizeof(PimLightmapPage));
     if (!pages) return;
     for (i32 i = 0; i < lmCount; ++i) pages[i].block = &lightmaps[i].probes[0]->x;
+    if (ms_pack.lightmaps == lightmaps) LmPack_Invalidate();            /* position / normal / sampleCounts change under a resident copy */
     ok(pimgpu_lightmap_embed(drawables, texIds, pages, lmCount, lightmaps[0].size), "LmPack_EmbedAttributes");
     free(pages);
 }
@@ -429,12 +470,32 @@ void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp)
 {
     const LmPack* pack = LmPack_Get();                                   /* lightmap.c:1211 */
     if (!scene || pack->lmCount <= 0 || !pack->lightmaps) return;
-    PimLightmapPage* pages = calloc((size_t)pack->lmCount, sizeof(PimLightmapPage));
+    PimLightmapPage* pages = lm_page_table(pack);
     if (!pages) return;
-    for (i32 i = 0; i < pack->lmCount; ++i) pages[i].block = &pack->lightmaps[i].probes[0]->x;   /* lightmap.c:95-110 */
     scene_refresh(scene);                                                /* PtScene_Update, lightmap.c:1209; its UpdateDists runs inside the bake call */
-    if (ok(pimgpu_lightmap_bake(scene->gpu, pages, pack->lmCount, pack->lmSize, pack->texelsPerMeter, timeSlice, spp > 1 ? spp : 1,
+    if (ms_lmMode == 0)
+    {
+        if (ok(pimgpu_lightmap_bake(scene->gpu, pages, pack->lmCount, pack->lmSize, pack->texelsPerMeter, timeSlice, spp > 1 ? spp : 1,
+            ms_counters.lmBake, ms_config.seed, ms_config.maxBounces, 0, -1), "LmPack_Bake"))
+            ms_counters.lmBake++;
+        free(pages);
+        return;
+    }
+    /* resident: the pages go up once (again whenever the pack is another one), every call bakes in HBM */
+    if (ms_lmSet && (ms_lmSetCount != pack->lmCount || ms_lmSetSize != pack->lmSize || ms_lmSetKey != (const void*)pack->lightmaps[0].probes[0]))
+        LmPack_Invalidate();
+    if (!ms_lmSet)
+    {
+        if (!ok(pimgpu_lightmap_set_create(pack->lmCount, pack->lmSize, &ms_lmSet), "LmPack_Bake") ||
+            !ok(pimgpu_lightmap_set_upload(ms_lmSet, pages), "LmPack_Bake")) { lm_set_drop(); free(pages); return; }
+        ms_lmSetCount = pack->lmCount; ms_lmSetSize = pack->lmSize; ms_lmSetKey = pack->lightmaps[0].probes[0];
+    }
+    if (ok(pimgpu_lightmap_set_bake(scene->gpu, ms_lmSet, pack->texelsPerMeter, timeSlice, spp > 1 ? spp : 1,
         ms_counters.lmBake, ms_config.seed, ms_config.maxBounces, 0, -1), "LmPack_Bake"))
+    {
         ms_counters.lmBake++;
+        ms_lmDeviceNewer = true;
+        if (ms_lmMode == 1) LmPack_Sync();                               /* host pages up to date after every call, as in the reference */
+    }
     free(pages);
 }

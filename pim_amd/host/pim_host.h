@@ -34,6 +34,7 @@ extern "C" {
 /* ---- the reference's plain types (math/types.h:52-73,152-157; same size and alignment) ---- */
 typedef int32_t i32;
 typedef uint32_t u32;
+typedef uint64_t u64;
 typedef struct float2_s { _Alignas(8) float x; float y; } float2;
 typedef struct float3_s { float x, y, z; } float3;
 typedef struct float4_s { _Alignas(16) float x; float y, z, w; } float4;
@@ -94,6 +95,28 @@ void Lightmap_Del(Lightmap* lm);                         /* :57 */
 LmPack* LmPack_Get(void);                                /* :61: the pack LmPack_Bake works on (ms_pack, lightmap.c:79) */
 void LmPack_Del(LmPack* pack);                           /* :67 */
 void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp);   /* :69, lightmap.c:1204-1223 */
+void Lightmap_Upload(Lightmap* lm);                      /* :59, lightmap.c:135-144: the kGiDirections probe layers go to the uploader below */
+
+/* the lightmap checkpoint: common/guid.h:7-12,24-26, io/types.h:36-39, assets/crate.h:9-33, lightmap.h:11,46-54,71-72
+ * (pim_crate.c; the file it writes is the reference's, byte for byte) */
+typedef struct Guid_s { _Alignas(16) u64 a; u64 b; } Guid;
+bool Guid_IsNull(Guid x);
+bool Guid_Equal(Guid lhs, Guid rhs);
+Guid Guid_FromStr(const char* str);
+Guid Guid_HashStr(const char* str);
+typedef struct FStream_s { void* handle; } FStream;
+enum { kCrateLen = 1024 };
+typedef struct Crate_s { FStream file; Guid ids[kCrateLen]; i32 offsets[kCrateLen]; i32 sizes[kCrateLen]; } Crate;
+bool Crate_Open(Crate* crate, const char* path);
+bool Crate_Close(Crate* crate);
+bool Crate_Get(Crate* crate, Guid id, void* dst, i32 size);
+bool Crate_Set(Crate* crate, Guid id, const void* src, i32 size);
+bool Crate_Rm(Crate* crate, Guid id);
+bool Crate_Stat(const Crate* crate, Guid id, i32* offsetOut, i32* sizeOut);
+#define kLmPackVersion 2
+typedef struct DiskLmPack_s { i32 version; i32 directions; i32 lmCount; i32 lmSize; i32 bytesPerLightmap; float texelsPerMeter; } DiskLmPack;
+bool LmPack_Save(Crate* crate, const LmPack* src);
+bool LmPack_Load(Crate* crate, LmPack* dst);
 
 /* rendering/cubemap.h:28-34,209-213 and math/types.h:513-517, math/ambcube.h:69-74 */
 typedef struct Cubemap_s { i32 size; i32 mipCount; float3* color[6]; float4* convolved[6]; } Cubemap;
@@ -134,6 +157,23 @@ void PtSys_Configure(const PtSysConfig* config);         /* before or after PtSy
 typedef struct PtSysCounters { uint32_t trace, traceRay, rayGen, cubemap, lmBake; } PtSysCounters;
 void PtSys_GetCounters(PtSysCounters* out);
 void PtTrace_DownloadAovs(PtTrace* trace);               /* with downloadAovs == 0: bring albedo / normal up to date now */
+
+/* vkrTexTable_Upload's stand-in (rendering/vulkan/vkr_textable.h; lightmap.c:142): Lightmap_Upload hands it layer `layer` of the
+ * page's 2D-array texture, size x size RGBA32F = `bytes` bytes at `data`.  None registered: Lightmap_Upload does nothing. */
+typedef void (*LmUploadFn)(vkrTextureId slot, i32 layer, const void* data, i32 bytes, void* user);
+void PtSys_SetLightmapUploader(LmUploadFn fn, void* user);
+
+/* LmPack_Bake with the pack's pages kept in HBM between calls (pimgpu_lightmap_set_*).  The reference bakes in place in host
+ * memory; its callers read the pages only in Lightmap_Upload (every 10 s, render_system.c:200-210) and LmPack_Save, so:
+ *   0  every call copies the pages to the device and probes | sampleCounts back (default: host pages are ALWAYS current, and a
+ *      caller may edit them between calls);
+ *   1  the pages go up once, every call copies probes | sampleCounts back (host pages current after every call);
+ *   2  nothing crosses PCIe in LmPack_Bake; Lightmap_Upload, LmPack_Save and LmPack_Sync bring the results to the host.
+ * In modes 1 and 2 a caller that writes the pages itself (not through LmPack_EmbedAttributes / LmPack_Load, which know)
+ * calls LmPack_Invalidate afterwards. */
+void LmPack_SetResident(i32 mode);
+void LmPack_Sync(void);
+void LmPack_Invalidate(void);
 
 /* explicit-argument forms (tests, tools): the same work with the counters' values passed in */
 PtScene* PtScene_NewFromSnapshot(const PimSceneDesc* snapshot);

@@ -68,6 +68,18 @@ def main(n):
     for a, b in zip(pg, po):
         assert_bits_equal(a, b, "sub-range pages")
 
+    # the same with pages resident in HBM: every context keeps a replica and bakes its tiles of it, the download merges them
+    hs = [p.copy() for p in pages]; po2 = [p.copy() for p in pages]
+    lm = api.LightmapSet(len(pages), S)
+    lm.upload(hs)
+    for passIndex, (slice_, spp) in enumerate([(1.0, 2), (0.6, 2)]):
+        lm.bake(g, 3.0, slice_, spp, passIndex=passIndex + 20, seed=5, maxBounces=4)
+        o.lightmap_bake(po2, S, 3.0, slice_, spp, passIndex=passIndex + 20, seed=5, maxBounces=4)
+    lm.download(hs)
+    for a, b in zip(hs, po2):
+        assert_bits_equal(a, b, "resident pages")
+    lm.close()
+
     g.rebuild_bvh()
     ro, rd = scenes.random_rays(sc, 5000, seed=2)
     assert g.intersect(ro, rd).tobytes() == o.intersect(ro, rd).tobytes()

@@ -202,3 +202,117 @@ def test_lightmap_pages_under_pim_names():
         assert (got.view(np.uint32) == w.view(np.uint32)).all() and got[S * S * 26:].sum() > 50
         host.Lightmap_Del(C.byref(lm))
         assert not lm.sampleCounts and lm.size == 0
+
+
+def test_lightmap_checkpoint_resumes_bit_exact(tmp_path):
+    """LmPack_Save / LmPack_Load (lightmap.c:1225-1308) around LmPack_Bake: a bake that is saved after its first pass,
+    dropped, loaded back (Lightmap_New + Crate_Get + Lightmap_Upload per page) and continued equals the uninterrupted bake
+    and the oracle bit for bit -- probes with their running lobe weights in .w, sampleCounts, position, normal; the
+    uploader sees the kGiDirections RGBA32F layers of every page (Lightmap_Upload, lightmap.c:135-144)"""
+    from tests.test_host_crate import Crate, Guid, Lightmap, LmPack
+    host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
+    libc = C.CDLL(None)
+    libc.calloc.restype = C.c_void_p
+    libc.calloc.argtypes = [C.c_size_t, C.c_size_t]
+    host.PtSys_Ok.restype = C.c_bool
+    host.LmPack_Get.restype = C.POINTER(LmPack)
+    host.PtScene_NewFromSnapshot.restype = C.c_void_p
+    host.PtScene_NewFromSnapshot.argtypes = [C.c_void_p]
+    host.LmPack_Bake.argtypes = [C.c_void_p, C.c_float, C.c_int32]
+    for f in ("Crate_Open", "Crate_Close", "LmPack_Save", "LmPack_Load"):
+        getattr(host, f).restype = C.c_bool
+    host.Crate_Open.argtypes = [C.POINTER(Crate), C.c_char_p]
+    seed, mb, S = 11, 3, 32
+    cfg = (C.c_int32 * 5)(seed, mb, 0, 1, -1)                    # PtSysConfig: seed, maxBounces, frameDt (default), downloadAovs, device
+    sc = scenes.cornell_box()
+    uploads = []
+    UPLOAD = C.CFUNCTYPE(None, C.c_uint32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p)
+
+    @UPLOAD
+    def on_upload(slot, layer, data, nbytes, user):
+        uploads.append((layer, nbytes, np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_float)), shape=(nbytes // 4,)).copy()))
+    host.PtSys_SetLightmapUploader(on_upload, None)
+
+    def fresh_pack():
+        pack = host.LmPack_Get()
+        host.LmPack_Del(pack)
+        pack.contents.lightmaps = C.cast(libc.calloc(1, C.sizeof(Lightmap)), C.POINTER(Lightmap))
+        pack.contents.lmCount, pack.contents.lmSize, pack.contents.texelsPerMeter = 1, S, 4.0
+        host.Lightmap_New(C.byref(pack.contents.lightmaps[0]), C.c_int32(S))
+        page = np.ctypeslib.as_array(C.cast(pack.contents.lightmaps[0].probes[0], C.POINTER(C.c_float)), shape=(S * S * 27,))
+        fill_page(page)
+        return pack, page
+
+    def fill_page(page):
+        pos = page[S * S * 20:S * S * 23].reshape(S, S, 3); nor = page[S * S * 23:S * S * 26].reshape(S, S, 3); cnt = page[S * S * 26:].reshape(S, S)
+        ys, xs = np.meshgrid(np.arange(4, 28), np.arange(4, 28), indexing="ij")
+        pos[4:28, 4:28, 0] = np.float32(-3.0) + np.float32(0.25) * xs.astype(np.float32); pos[4:28, 4:28, 1] = -4.95
+        pos[4:28, 4:28, 2] = np.float32(-3.0) + np.float32(0.25) * ys.astype(np.float32)
+        nor[4:28, 4:28, 1] = 1.0; cnt[4:28, 4:28] = 1.0
+
+    # the oracle's two passes
+    o = OracleScene(sc.desc, accel=1)
+    want = np.zeros(S * S * 27, np.float32); fill_page(want)
+    o.lightmap_bake([want], S, 4.0, 1.0, 3, passIndex=0, seed=seed, maxBounces=mb)
+    o.lightmap_bake([want], S, 4.0, 1.0, 2, passIndex=1, seed=seed, maxBounces=mb)
+
+    # uninterrupted
+    host.PtSys_Configure(cfg); host.PtSys_Init()
+    assert host.PtSys_Ok()
+    scene = C.c_void_p(host.PtScene_NewFromSnapshot(C.byref(sc.desc)))
+    assert scene
+    pack, page = fresh_pack()
+    assert len(uploads) == 5 and all(n == S * S * 16 for _, n, _ in uploads)         # Lightmap_New ends with Lightmap_Upload (lightmap.c:122)
+    host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(3)); host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(2))
+    straight = page.copy()
+    assert_bits_equal(straight, want, "uninterrupted bake")
+    host.PtScene_Del(scene)
+
+    # the same with the pages resident in HBM: nothing comes back before LmPack_Sync (mode 2) / after every call (mode 1)
+    for mode in (2, 1):
+        host.PtSys_Configure(cfg)
+        scene = C.c_void_p(host.PtScene_NewFromSnapshot(C.byref(sc.desc)))
+        pack, page = fresh_pack()
+        host.LmPack_SetResident(C.c_int32(mode))
+        host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(3))
+        if mode == 2:
+            assert not page[:S * S * 20].any()                   # still the zeroed probes on the host
+        host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(2))
+        if mode == 2:
+            assert not page[:S * S * 20].any()
+            host.LmPack_Sync()
+        assert_bits_equal(page, straight, f"resident bake, mode {mode}")
+        host.LmPack_SetResident(C.c_int32(0))
+        host.PtScene_Del(scene)
+
+    # saved after pass 0, dropped, loaded, continued
+    host.PtSys_Configure(cfg)
+    scene = C.c_void_p(host.PtScene_NewFromSnapshot(C.byref(sc.desc)))
+    pack, page = fresh_pack()
+    host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(3))
+    after_first = page.copy()
+    crate = Crate()
+    path = str(tmp_path / "bake.crate").encode()
+    assert host.Crate_Open(C.byref(crate), path)
+    assert host.LmPack_Save(C.byref(crate), pack)
+    assert host.Crate_Close(C.byref(crate))
+    assert os.path.getsize(path) == 24576 + 24 + S * S * 108
+    host.LmPack_Del(pack)
+    assert pack.contents.lmCount == 0 and not pack.contents.lightmaps
+    del uploads[:]
+    assert host.Crate_Open(C.byref(crate), path)
+    assert host.LmPack_Load(C.byref(crate), pack)
+    assert host.Crate_Close(C.byref(crate))
+    assert (pack.contents.lmCount, pack.contents.lmSize, pack.contents.texelsPerMeter) == (1, S, 4.0)
+    page = np.ctypeslib.as_array(C.cast(pack.contents.lightmaps[0].probes[0], C.POINTER(C.c_float)), shape=(S * S * 27,))
+    assert_bits_equal(page, after_first, "loaded page")
+    # Lightmap_New's upload of the zeroed page, then LmPack_Load's upload of the loaded one: layer i = probes[i]
+    assert [l for l, _, _ in uploads] == [0, 1, 2, 3, 4] * 2
+    for layer, nbytes, data in uploads[5:]:
+        assert nbytes == S * S * 16
+        assert_bits_equal(data, after_first[S * S * 4 * layer:S * S * 4 * (layer + 1)], f"uploaded layer {layer}")
+    host.LmPack_Bake(scene, C.c_float(1.0), C.c_int32(2))
+    assert_bits_equal(page, straight, "resumed bake")
+    host.LmPack_Del(pack)
+    host.PtScene_Del(scene)
+    host.PtSys_SetLightmapUploader(None, None)

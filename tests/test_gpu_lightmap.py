@@ -35,3 +35,35 @@ def test_cornell_bake_bit_exact():
     changed = np.nonzero(cnt_b != cnt_a)[0]
     assert changed.size > 0 and changed.min() >= begin and changed.max() < end
     g.close()
+
+
+def test_resident_pages_bake_like_host_pages():
+    """pimgpu_lightmap_set_*: pages uploaded once, three bake calls (full, time-sliced, a texel sub-range) with nothing crossing
+    PCIe in between, one download: the oracle's pages bit for bit; position / normal of the host pages are left alone"""
+    gpu_init()
+    sc = scenes.textured_cornell()
+    S = 64
+    pages = scenes.lightmap_pages_for(sc, S, 2.0, max_pages=2)
+    host = [p.copy() for p in pages]
+    po = [p.copy() for p in pages]
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    lm = api.LightmapSet(len(pages), S)
+    lm.upload(host)
+    calls = [(1.0, 2, 0, 0, -1), (0.5, 3, 1, 0, -1), (1.0, 1, 2, S * S // 4, S * S // 2)]
+    for slice_, spp, passIndex, begin, end in calls:
+        lm.bake(g, 2.0, slice_, spp, passIndex=passIndex, seed=9, maxBounces=4, texelBegin=begin, texelEnd=end)
+        o.lightmap_bake(po, S, 2.0, slice_, spp, passIndex=passIndex, seed=9, maxBounces=4, texelBegin=begin, texelEnd=end)
+    for a, b in zip(host, pages):
+        assert_bits_equal(a, b, "host pages before the download")          # nothing came back yet
+    for h in host:
+        h[S * S * 20:S * S * 26] += 1.0                                     # the download must not touch position | normal
+    lm.download(host)
+    for h, b, p0 in zip(host, po, pages):
+        assert_bits_equal(h[:S * S * 20], b[:S * S * 20], "probes")
+        assert_bits_equal(h[S * S * 26:], b[S * S * 26:], "sampleCounts")
+        assert_bits_equal(h[S * S * 20:S * S * 26], p0[S * S * 20:S * S * 26] + np.float32(1.0), "position | normal")
+    assert (host[0][:S * S * 20] != 0).any()
+    with pytest.raises(api.PimGpuError):
+        api.LightmapSet(0, S)
+    lm.close(); g.close()
