@@ -428,6 +428,21 @@ int pimgpu_lightmap_chart_layout(PimChartNode* nodes, const int32_t* chartFirst,
 int pimgpu_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartFirst, int32_t chartCount, const int32_t* maskSizes,
     const int64_t* maskOffsets, uint8_t* masks);
 
+/* atlases_create (lightmap.c:845-874) as ONE worker of AtlasFn (:779-823) runs it: the charts, taken in `order` (chart_sort's
+ * result, :648-660), are placed one after the other at the first translation -- row-major from the worker's row hint, atlas by
+ * atlas from its atlas hint (atlas_search :680-721, mask_find :261-282) -- where their mask overlaps nothing already placed
+ * (mask_fits :174-207), and written there (mask_write :209-230).  With several workers the reference's result depends on
+ * thread timing; this is the result of one.  masks / maskOffsets / maskSizes / areas as pimgpu_lightmap_chart_layout and
+ * _chart_masks leave them, atlasCount from atlas_estimate (:825-843).  Out, by chart: translations[2c], [2c+1] and
+ * atlasIndex[c]; *usedAtlases = atlases that took a chart (:862-870) = the pages LmPack_Pack makes.
+ * A chart that fits in none of the atlasCount atlases after the worker's full retry makes the reference's AtlasFn spin for ever
+ * (:808-818; atlas_estimate counts bounds without margins and does run short): here one more atlas is opened for it, up to
+ * atlasCap in all (>= atlasCount; everything placed before that point is where the reference put it).  PIMGPU_E_LIMIT when a
+ * chart is larger than an atlas or atlasCap is reached. */
+int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets, const int32_t* maskSizes, const float* areas,
+    const int32_t* order, int32_t chartCount, int32_t atlasSize, int32_t atlasCount, int32_t atlasCap,
+    int32_t* translations, int32_t* atlasIndex, int32_t* usedAtlases);
+
 /* EmbedAttributes / EmbedTaskFn (lightmap.c:941-1045), the last step of LmPack_Pack (:1092) and the producer of
  * LmPack_Bake's inputs: every texel of every page takes the mapped triangle (texIndices[iVert].w == the page's texture
  * id; drawables with MatFlag_Sky | MatFlag_Lava and NULL meshes skipped) whose signed 2D distance (sdTriangle2D on

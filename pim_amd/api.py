@@ -118,7 +118,7 @@ EXPORTS = [
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc", "pimgpu_init_devices", "pimgpu_device_count",
-    "pimgpu_lightmap_set_create", "pimgpu_lightmap_set_destroy", "pimgpu_lightmap_set_upload", "pimgpu_lightmap_set_download", "pimgpu_lightmap_set_bake",
+    "pimgpu_lightmap_set_create", "pimgpu_lightmap_set_destroy", "pimgpu_lightmap_set_upload", "pimgpu_lightmap_set_download", "pimgpu_lightmap_set_bake", "pimgpu_lightmap_atlas_place",
 ]
 
 _LIB = None
@@ -461,6 +461,17 @@ def lightmap_chart_masks(nodes, chartFirst):
     masks = np.full(int(lens.sum()), 7, np.uint8)
     check(lib.pimgpu_lightmap_chart_masks(_ptr(nodes), _ptr(first), C.c_int32(nc), _ptr(sizes), _ptr(offsets), _ptr(masks)), "pimgpu_lightmap_chart_masks")
     return areas, sizes, offsets, masks
+
+
+def lightmap_atlas_place(masks, offsets, sizes, areas, order, atlasSize, atlasCount, atlasCap=0):
+    """atlases_create (rendering/lightmap.c:845-874) as one worker runs it -> (translations (charts, 2), atlasIndex, usedAtlases)"""
+    nc = int(np.asarray(order).shape[0])
+    masks = np.ascontiguousarray(masks, np.uint8); offsets = np.ascontiguousarray(offsets, np.int64)
+    sizes = np.ascontiguousarray(sizes, np.int32); areas = f32(areas); order = np.ascontiguousarray(order, np.int32)
+    tr, idx, used = np.full((nc, 2), -7, np.int32), np.full(nc, -7, np.int32), C.c_int32(-1)
+    check(load_library().pimgpu_lightmap_atlas_place(_ptr(masks), _ptr(offsets), _ptr(sizes), _ptr(areas), _ptr(order), C.c_int32(nc),
+          C.c_int32(atlasSize), C.c_int32(atlasCount), C.c_int32(atlasCap), _ptr(tr), _ptr(idx), C.byref(used)), "pimgpu_lightmap_atlas_place")
+    return tr, idx, used.value
 
 
 def brdf_lut_bake(texels, prevSamples, numSamples, seed=0):

@@ -12,6 +12,8 @@
 #include "pt_api.h"
 
 #include <vector>
+#include <cstring>
+#include <algorithm>
 
 namespace pt {
 
@@ -340,6 +342,114 @@ __global__ __launch_bounds__(256) void k_chart_masks(ChartMaskArgs a)
 using namespace pt;
 
 namespace {
+
+
+/* ---------------------------------------------------------------------------------------------- */
+/* atlases_create (rendering/lightmap.c:845-874): first-fit placement of every chart's mask, in the sorted order.
+ *
+ * The reference hands the sorted charts to its worker threads through one counter (AtlasFn, :779-823); every worker scans an
+ * atlas row-major for the first translation at which the chart's mask overlaps nothing (mask_find :261-282, mask_fits
+ * :174-207), locks the atlas, re-checks and writes (atlas_search :680-721).  Which chart gets which place then depends on
+ * thread timing.  The order of ONE worker is taken here: chart i is placed before chart i + 1 is looked at, with the worker's
+ * three hints -- keep searching from the atlas and row of the previous chart as long as the areas shrink by less than a
+ * tenth (:801-806), start over from atlas 0 when the search fails (:808-818).
+ * What is parallel is the scan itself: the candidate translations of an atlas, taken row-major from the starting row, are
+ * tested kAtlasThreads at a time by ONE workgroup (a chart's placement depends on all placements before it: there is nothing
+ * for a second workgroup to do), the lowest candidate that fits wins -- the one the sequential scan meets first.
+ * A chart that fits in none of the atlas_estimate()d atlases even after the worker's full retry makes the reference spin for
+ * ever (:808-818; the estimate counts the charts' bounds without their margins, so it does run short).  Here the run goes on
+ * where the reference stops making progress: one more atlas is opened, up to atlasCap, and the chart goes there; every
+ * placement up to that point is the reference's.  status[0] stays -1, or receives the chart that fits nowhere (larger than an
+ * atlas, or atlasCap reached); status[1] = atlases in use at the end.
+ */
+static constexpr int kAtlasThreads = 1024;
+#define PT_ROW_RESET (-(1 << 20))              /* lightmap.c:37 */
+struct AtlasArgs
+{
+    const uint8_t* masks; const int64_t* maskOffsets; const int32_t* maskSizes; const float* areas; const int32_t* order;
+    int32_t chartCount, atlasSize, atlasCount, atlasCap;
+    uint8_t* atlases; int32_t* atlasCharts; int32_t* translations; int32_t* atlasIndex; int32_t* status;
+};
+
+__global__ __launch_bounds__(kAtlasThreads) void k_atlas_place(AtlasArgs a)
+{
+    __shared__ int32_t sBest;
+    const int32_t tid = (int32_t)threadIdx.x;
+    const int32_t S = a.atlasSize;
+    int32_t prevAtlas = 0, prevRow = PT_ROW_RESET;
+    float prevArea = (float)(1 << 23);
+    int32_t atlasCount = a.atlasCount;
+    for (int32_t i = 0; i < a.chartCount; ++i)
+    {
+        const int32_t c = a.order[i];
+        const uint8_t* __restrict__ item = a.masks + a.maskOffsets[c];
+        const int32_t bw = a.maskSizes[2 * c], bh = a.maskSizes[2 * c + 1];
+        const float area = a.areas[c];
+        if (area < (prevArea * 0.9f)) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
+        bool placed = false;
+        for (int attempt = 0; attempt < 3 && !placed; ++attempt)
+        {
+            for (int32_t at = prevAtlas; at < atlasCount && !placed; ++at)
+            {
+                uint8_t* atlas = a.atlases + (size_t)at * (size_t)S * (size_t)S;
+                const int32_t rangeX = S - bw, rangeY = S - bh;
+                const int32_t y0 = (prevRow != PT_ROW_RESET) ? prevRow : 0;
+                int64_t found = -1;
+                if (rangeX > 0 && rangeY > y0)
+                {
+                    const int64_t total = (int64_t)(rangeY - y0) * rangeX;
+                    for (int64_t base = 0; base < total && found < 0; base += kAtlasThreads)
+                    {
+                        if (tid == 0) sBest = 0x7fffffff;
+                        __syncthreads();
+                        const int64_t idx = base + tid;
+                        if (idx < total)
+                        {
+                            const int32_t y = y0 + (int32_t)(idx / rangeX), x = (int32_t)(idx % rangeX);
+                            bool fits = true;                                        /* mask_fits: the bounds hold by the ranges */
+                            for (int32_t by = 0; by < bh && fits; ++by)
+                            {
+                                const uint8_t* arow = atlas + (size_t)(y + by) * (size_t)S + x;
+                                const uint8_t* brow = item + (size_t)by * (size_t)bw;
+                                for (int32_t bx = 0; bx < bw; ++bx) if ((brow[bx] & arow[bx]) != 0) { fits = false; break; }
+                            }
+                            if (fits) atomicMin(&sBest, tid);
+                        }
+                        __syncthreads();
+                        const int32_t best = sBest;
+                        __syncthreads();
+                        if (best != 0x7fffffff) found = base + best;
+                    }
+                }
+                if (found >= 0)
+                {
+                    const int32_t ty = y0 + (int32_t)(found / rangeX), tx = (int32_t)(found % rangeX);
+                    for (int32_t k = tid; k < bw * bh; k += kAtlasThreads)              /* mask_write, lightmap.c:209-230 */
+                    {
+                        const uint8_t v = item[k];
+                        if (v) atlas[(size_t)(ty + k / bw) * (size_t)S + (size_t)(tx + k % bw)] = v;
+                    }
+                    __threadfence();             /* the next chart's scan reads these bytes from other lanes' writes */
+                    __syncthreads();
+                    if (tid == 0) { a.translations[2 * c] = tx; a.translations[2 * c + 1] = ty; a.atlasIndex[c] = at; a.atlasCharts[at] += 1; }
+                    prevAtlas = at; prevRow = ty;
+                    placed = true;
+                }
+                else prevRow = PT_ROW_RESET;
+            }
+            if (!placed && attempt == 0) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
+            if (!placed && attempt == 1)
+            {
+                /* the full search found nothing.  An empty atlas takes the chart iff its mask is smaller than the atlas on both axes */
+                if (atlasCount >= a.atlasCap || bw >= S || bh >= S) break;
+                prevArea = area; prevAtlas = atlasCount; prevRow = PT_ROW_RESET;
+                ++atlasCount;
+            }
+        }
+        if (!placed) { if (tid == 0) { a.status[0] = c; a.status[1] = atlasCount; } return; }
+    }
+    if (tid == 0) a.status[1] = atlasCount;
+}
 
 struct DevBuf
 {
@@ -670,6 +780,72 @@ int pimgpu_lightmap_chart_masks(const PimChartNode* nodes, const int32_t* chartF
         if (bytes) PT_HIP(hipMemcpyAsync(masks + maskOffsets[c], (uint8_t*)maskBuf.p + maskOffsets[c], bytes, hipMemcpyDeviceToHost, st));
     }
     PT_HIP(hipStreamSynchronize(st));
+    return PIMGPU_OK;
+}
+
+
+int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets, const int32_t* maskSizes, const float* areas,
+    const int32_t* order, int32_t chartCount, int32_t atlasSize, int32_t atlasCount, int32_t atlasCap, int32_t* translations, int32_t* atlasIndex, int32_t* usedAtlases)
+{
+    if (usedAtlases) *usedAtlases = 0;
+    int rc = check_ready(); if (rc) return rc;
+    if (atlasCap < atlasCount) atlasCap = atlasCount;
+    if (chartCount < 0 || atlasSize <= 0 || atlasSize > 16384 || atlasCount <= 0 || atlasCap > (1 << 20) || (chartCount > 0 && (!masks || !maskOffsets || !maskSizes || !areas || !order || !translations || !atlasIndex)))
+    { set_error("lightmap_atlas_place: bad argument"); return PIMGPU_E_INVALID; }
+    if (chartCount == 0) return PIMGPU_OK;
+    int64_t total = 0;
+    std::vector<uint8_t> seen((size_t)chartCount, 0);
+    for (int32_t c = 0; c < chartCount; ++c)
+    {
+        const int64_t sx = maskSizes[2 * c], sy = maskSizes[2 * c + 1];
+        if (sx <= 0 || sy <= 0 || sx > 65536 || sy > 65536 || maskOffsets[c] < 0) { set_error("lightmap_atlas_place: chart %d has a bad mask size or offset", c); return PIMGPU_E_INVALID; }
+        total = std::max<int64_t>(total, maskOffsets[c] + sx * sy);
+        if (order[c] < 0 || order[c] >= chartCount || seen[(size_t)order[c]]) { set_error("lightmap_atlas_place: order[] is not a permutation of the charts"); return PIMGPU_E_INVALID; }
+        seen[(size_t)order[c]] = 1;
+    }
+    hipStream_t st = g_lib.stream;
+    const size_t aBytes = (size_t)atlasSize * (size_t)atlasSize;
+    DevBuf maskBuf, offBuf, sizeBuf, areaBuf, orderBuf, atlasBuf, outBuf;
+    if ((rc = maskBuf.alloc((size_t)total))) return rc;
+    if ((rc = offBuf.alloc(8 * (size_t)chartCount))) return rc;
+    if ((rc = sizeBuf.alloc(8 * (size_t)chartCount))) return rc;
+    if ((rc = areaBuf.alloc(4 * (size_t)chartCount))) return rc;
+    if ((rc = orderBuf.alloc(4 * (size_t)chartCount))) return rc;
+    if ((rc = atlasBuf.alloc(aBytes * (size_t)atlasCap))) return rc;
+    const size_t outInts = 3 * (size_t)chartCount + (size_t)atlasCap + 4;
+    if ((rc = outBuf.alloc(4 * outInts))) return rc;
+    PT_HIP(hipMemcpyAsync(maskBuf.p, masks, (size_t)total, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(offBuf.p, maskOffsets, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(sizeBuf.p, maskSizes, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(areaBuf.p, areas, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(orderBuf.p, order, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(atlasBuf.p, 0, aBytes * (size_t)atlasCap, st));
+    PT_HIP(hipMemsetAsync(outBuf.p, 0xff, 4 * outInts, st));            /* -1: not placed / no failure */
+    AtlasArgs a;
+    a.masks = (const uint8_t*)maskBuf.p; a.maskOffsets = (const int64_t*)offBuf.p; a.maskSizes = (const int32_t*)sizeBuf.p;
+    a.areas = (const float*)areaBuf.p; a.order = (const int32_t*)orderBuf.p; a.chartCount = chartCount; a.atlasSize = atlasSize; a.atlasCount = atlasCount; a.atlasCap = atlasCap;
+    a.atlases = (uint8_t*)atlasBuf.p;
+    int32_t* out = (int32_t*)outBuf.p;
+    a.translations = out; a.atlasIndex = out + 2 * (size_t)chartCount; a.atlasCharts = out + 3 * (size_t)chartCount; a.status = a.atlasCharts + atlasCap;
+    PT_HIP(hipMemsetAsync(a.atlasCharts, 0, 4 * (size_t)atlasCap, st));
+    k_atlas_place<<<1, kAtlasThreads, 0, st>>>(a);
+    PT_HIP(hipGetLastError());
+    std::vector<int32_t> host(outInts);
+    PT_HIP(hipMemcpyAsync(host.data(), out, 4 * outInts, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    const int32_t failedChart = host[3 * (size_t)chartCount + (size_t)atlasCap];
+    if (failedChart >= 0)
+    {
+        set_error("lightmap_atlas_place: chart %d (mask %d x %d) fits in none of the %d atlases of %d^2, %d more allowed (the reference's AtlasFn does not return here, lightmap.c:808-818)",
+            failedChart, maskSizes[2 * failedChart], maskSizes[2 * failedChart + 1], host[3 * (size_t)chartCount + (size_t)atlasCap + 1], atlasSize,
+            atlasCap - host[3 * (size_t)chartCount + (size_t)atlasCap + 1]);
+        return PIMGPU_E_LIMIT;
+    }
+    memcpy(translations, host.data(), 8 * (size_t)chartCount);
+    memcpy(atlasIndex, host.data() + 2 * (size_t)chartCount, 4 * (size_t)chartCount);
+    int32_t used = 0;
+    for (int32_t i = 0; i < atlasCap; ++i) if (host[3 * (size_t)chartCount + (size_t)i] > 0) ++used;        /* atlases_create, lightmap.c:862-870 */
+    if (usedAtlases) *usedAtlases = used;
     return PIMGPU_OK;
 }
 

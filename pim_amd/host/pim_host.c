@@ -69,6 +69,7 @@ void PtSys_Configure(const PtSysConfig* config)
 }
 
 void PtSys_GetCounters(PtSysCounters* out) { if (out) *out = ms_counters; }
+uint32_t PtSys_Seed(void) { return ms_config.seed; }
 void PtSys_SetSceneProvider(PtSceneProviderFn fn, void* user) { ms_provider = fn; ms_providerUser = user; }
 
 void PtSys_Init(void)
@@ -398,6 +399,10 @@ void Lightmap_New(Lightmap* lm, i32 size)
     lm->position = (float3*)(allocation + texelcount * 20);
     lm->normal = (float3*)(allocation + texelcount * 23);
     lm->sampleCounts = allocation + texelcount * 26;
+    /* vkrTexTable_Alloc (lightmap.c:112-120) gives every page a texture slot of its own; chartnodes_assign stamps slot.index into
+     * the meshes and EmbedAttributes finds the page's triangles by it (:919-921, :962).  The renderer is not here: ids count up. */
+    static u32 nextSlot = 1;
+    lm->slot.version = 1; lm->slot.type = 0; lm->slot.index = nextSlot++ & 0x1fffffu;
     Lightmap_Upload(lm);                                                 /* lightmap.c:122 */
 }
 

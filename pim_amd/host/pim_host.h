@@ -95,6 +95,7 @@ void Lightmap_Del(Lightmap* lm);                         /* :57 */
 LmPack* LmPack_Get(void);                                /* :61: the pack LmPack_Bake works on (ms_pack, lightmap.c:79) */
 void LmPack_Del(LmPack* pack);                           /* :67 */
 void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp);   /* :69, lightmap.c:1204-1223 */
+LmPack LmPack_Pack(i32 atlasSize, float texelsPerUnit, float distThresh, float degThresh);   /* :62-66, lightmap.c:1047-1102 (pim_lmpack.c) */
 void Lightmap_Upload(Lightmap* lm);                      /* :59, lightmap.c:135-144: the kGiDirections probe layers go to the uploader below */
 
 /* the lightmap checkpoint: common/guid.h:7-12,24-26, io/types.h:36-39, assets/crate.h:9-33, lightmap.h:11,46-54,71-72
@@ -157,6 +158,20 @@ void PtSys_Configure(const PtSysConfig* config);         /* before or after PtSy
 typedef struct PtSysCounters { uint32_t trace, traceRay, rayGen, cubemap, lmBake; } PtSysCounters;
 void PtSys_GetCounters(PtSysCounters* out);
 void PtTrace_DownloadAovs(PtTrace* trace);               /* with downloadAovs == 0: bring albedo / normal up to date now */
+
+/* LmPack_Pack reads Entities_Get() / Mesh_Get() (lightmap.c:725-741) and writes the lightmap uvs and texture ids it assigns INTO
+ * the meshes (uvs.zw, texIndices.w, :919-930).  The provider fills *out with the draw table; its mesh arrays are the engine's
+ * own, writable, float4 uvs[length] and int4 texIndices[length]. */
+typedef bool (*PtDrawablesProviderFn)(PimDrawables* out, void* user);
+void PtSys_SetDrawablesProvider(PtDrawablesProviderFn fn, void* user);
+uint32_t PtSys_Seed(void);                               /* PtSysConfig.seed as configured */
+/* the same with the draw table and the seed of chart_split's streams passed in; a zeroed pack and LmPack_LastError() on failure */
+LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsPerUnit, float distThresh, float degThresh, uint32_t seed);
+const char* LmPack_LastError(void);
+/* the packer's sequential steps on their own (tests): chart_group with chart_split (lightmap.c:563-636; nodes are reordered chart
+ * by chart, chartFirst[count + 1], returns the chart count or -1) and chart_sort (:648-660; order[i] = chart in place i) */
+i32 LmPack_GroupCharts(PimChartNode* nodes, i32 nodeCount, float distThresh, float degThresh, float maxWidth, uint32_t seed, i32* chartFirst);
+void LmPack_SortCharts(const float* areas, i32 chartCount, i32* order);
 
 /* vkrTexTable_Upload's stand-in (rendering/vulkan/vkr_textable.h; lightmap.c:142): Lightmap_Upload hands it layer `layer` of the
  * page's 2D-array texture, size x size RGBA32F = `bytes` bytes at `data`.  None registered: Lightmap_Upload does nothing. */
