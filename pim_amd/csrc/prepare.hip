@@ -13,6 +13,7 @@
 
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 namespace pt {
@@ -451,6 +452,145 @@ __global__ __launch_bounds__(kAtlasThreads) void k_atlas_place(AtlasArgs a)
     if (tid == 0) a.status[1] = atlasCount;
 }
 
+
+/*
+ * The same search with the atlas as BITS in LDS.  mask_tri writes 0xff or nothing (lightmap.c:255), so a texel of an atlas is
+ * one bit; an atlas of up to 1024^2 texels -- the size the reference packs (render_system.c:176) -- is 128 KiB and fits the
+ * CU's 160 KiB of LDS beside the chart's own mask (as bit rows, <= kItemWordsLds 64-bit words; a larger one stays in HBM).
+ * A candidate translation is then tested row by row with 64 texels per AND, on LDS words every lane of a wave shares
+ * (broadcast reads), instead of byte by byte through the vector L1: 27 -> ~3 us per chart.  The atlas in LDS is written
+ * back to HBM (atlasBits) only when the search moves to another atlas.
+ */
+static constexpr int kAtlasBitsMaxSize = 1024;
+static constexpr int kAtlasRowWordsMax = kAtlasBitsMaxSize / 64;
+static constexpr int kItemWordsLds = 3584;                     /* 28 KiB: a 345 x 345 chart (a third of the atlas + margins) has 2070 */
+struct AtlasBitArgs
+{
+    AtlasArgs a;
+    unsigned long long* atlasBits;      /* [atlasCap][S * rowWords]: atlases not in LDS at the moment; zeroed by the host */
+    unsigned long long* itemBits;       /* [S * rowWords]: bit rows of a chart too large for LDS */
+};
+
+__global__ __launch_bounds__(kAtlasThreads) void k_atlas_place_bits(AtlasBitArgs g)
+{
+    const AtlasArgs& a = g.a;
+    __shared__ unsigned long long sAtlas[kAtlasBitsMaxSize * kAtlasRowWordsMax];
+    __shared__ unsigned long long sItem[kItemWordsLds];
+    __shared__ int32_t sBest;
+    const int32_t tid = (int32_t)threadIdx.x;
+    const int32_t S = a.atlasSize;
+    const int32_t rowWords = (S + 63) >> 6;
+    const int32_t atlasWords = S * rowWords;
+    int32_t prevAtlas = 0, prevRow = PT_ROW_RESET;
+    float prevArea = (float)(1 << 23);
+    int32_t atlasCount = a.atlasCount;
+    int32_t resident = -1;                                      /* the atlas whose bits are in LDS */
+    for (int32_t i = 0; i < a.chartCount; ++i)
+    {
+        const int32_t c = a.order[i];
+        const uint8_t* __restrict__ item = a.masks + a.maskOffsets[c];
+        const int32_t bw = a.maskSizes[2 * c], bh = a.maskSizes[2 * c + 1];
+        const float area = a.areas[c];
+        if (area < (prevArea * 0.9f)) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
+        /* the chart's mask as bit rows */
+        const int32_t itemRowWords = (bw + 63) >> 6;
+        const int32_t itemWords = bh * itemRowWords;
+        const bool itemInLds = itemWords <= kItemWordsLds;
+        for (int32_t w = tid; w < itemWords; w += kAtlasThreads)
+        {
+            const int32_t by = w / itemRowWords, x0 = (w % itemRowWords) * 64;
+            const uint8_t* brow = item + (size_t)by * (size_t)bw;
+            unsigned long long bits = 0ull;
+            const int32_t n = min(64, bw - x0);
+            for (int32_t b = 0; b < n; ++b) if (brow[x0 + b]) bits |= 1ull << b;
+            if (itemInLds) sItem[w] = bits; else g.itemBits[w] = bits;
+        }
+        if (!itemInLds) __threadfence();
+        __syncthreads();
+        bool placed = false;
+        for (int attempt = 0; attempt < 3 && !placed; ++attempt)
+        {
+            for (int32_t at = prevAtlas; at < atlasCount && !placed; ++at)
+            {
+                if (resident != at)
+                {
+                    /* swap the LDS atlas: write the resident one back, bring this one in */
+                    if (resident >= 0) for (int32_t w = tid; w < atlasWords; w += kAtlasThreads) g.atlasBits[(size_t)resident * atlasWords + w] = sAtlas[w];
+                    __threadfence();
+                    __syncthreads();
+                    for (int32_t w = tid; w < atlasWords; w += kAtlasThreads) sAtlas[w] = g.atlasBits[(size_t)at * atlasWords + w];
+                    resident = at;
+                    __syncthreads();
+                }
+                const int32_t rangeX = S - bw, rangeY = S - bh;
+                const int32_t y0 = (prevRow != PT_ROW_RESET) ? prevRow : 0;
+                int64_t found = -1;
+                if (rangeX > 0 && rangeY > y0)
+                {
+                    const int64_t total = (int64_t)(rangeY - y0) * rangeX;
+                    for (int64_t base = 0; base < total && found < 0; base += kAtlasThreads)
+                    {
+                        if (tid == 0) sBest = 0x7fffffff;
+                        __syncthreads();
+                        const int64_t idx = base + tid;
+                        if (idx < total)
+                        {
+                            const int32_t y = y0 + (int32_t)(idx / rangeX), x = (int32_t)(idx % rangeX);
+                            bool fits = true;
+                            for (int32_t by = 0; by < bh && fits; ++by)
+                            {
+                                const unsigned long long* arow = sAtlas + (y + by) * rowWords;
+                                for (int32_t k = 0; k < itemRowWords; ++k)
+                                {
+                                    const unsigned long long iw = itemInLds ? sItem[by * itemRowWords + k] : g.itemBits[by * itemRowWords + k];
+                                    if (!iw) continue;
+                                    const int32_t pos = x + 64 * k, wi = pos >> 6, sh = pos & 63;
+                                    unsigned long long aw = arow[wi] >> sh;
+                                    if (sh && wi + 1 < rowWords) aw |= arow[wi + 1] << (64 - sh);
+                                    if (aw & iw) { fits = false; break; }
+                                }
+                            }
+                            if (fits) atomicMin(&sBest, tid);
+                        }
+                        __syncthreads();
+                        const int32_t best = sBest;
+                        __syncthreads();
+                        if (best != 0x7fffffff) found = base + best;
+                    }
+                }
+                if (found >= 0)
+                {
+                    const int32_t ty = y0 + (int32_t)(found / rangeX), tx = (int32_t)(found % rangeX);
+                    for (int32_t w = tid; w < itemWords; w += kAtlasThreads)                 /* mask_write, lightmap.c:209-230 */
+                    {
+                        const unsigned long long iw = itemInLds ? sItem[w] : g.itemBits[w];
+                        if (!iw) continue;
+                        const int32_t by = w / itemRowWords, pos = tx + 64 * (w % itemRowWords), wi = pos >> 6, sh = pos & 63;
+                        unsigned long long* arow = sAtlas + (ty + by) * rowWords;
+                        atomicOr(&arow[wi], iw << sh);
+                        if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], iw >> (64 - sh));
+                    }
+                    __syncthreads();
+                    if (tid == 0) { a.translations[2 * c] = tx; a.translations[2 * c + 1] = ty; a.atlasIndex[c] = at; a.atlasCharts[at] += 1; }
+                    prevAtlas = at; prevRow = ty;
+                    placed = true;
+                }
+                else prevRow = PT_ROW_RESET;
+            }
+            if (!placed && attempt == 0) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
+            if (!placed && attempt == 1)
+            {
+                if (atlasCount >= a.atlasCap || bw >= S || bh >= S) break;
+                prevArea = area; prevAtlas = atlasCount; prevRow = PT_ROW_RESET;
+                ++atlasCount;
+            }
+        }
+        if (!placed) { if (tid == 0) { a.status[0] = c; a.status[1] = atlasCount; } return; }
+        __syncthreads();                                         /* sItem is rebuilt for the next chart */
+    }
+    if (tid == 0) a.status[1] = atlasCount;
+}
+
 struct DevBuf
 {
     void* p = nullptr;
@@ -805,13 +945,23 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     }
     hipStream_t st = g_lib.stream;
     const size_t aBytes = (size_t)atlasSize * (size_t)atlasSize;
-    DevBuf maskBuf, offBuf, sizeBuf, areaBuf, orderBuf, atlasBuf, outBuf;
+    /* any covered texel is 0xff (mask_tri, lightmap.c:255): the bit form of the search relies on it */
+    {
+        bool bad = false;
+        for (int64_t k = 0; k < total; ++k) { const uint8_t b = masks[k]; bad |= (b != 0) & (b != 0xff); }
+        if (bad) { set_error("lightmap_atlas_place: a mask holds a byte that is neither 0 nor 0xff"); return PIMGPU_E_INVALID; }
+    }
+    const bool asBits = atlasSize <= kAtlasBitsMaxSize && !getenv("PIMGPU_ATLAS_BYTES");      /* the byte form: larger atlases, and A/B runs of the tests */
+    const size_t rowWords = ((size_t)atlasSize + 63) / 64, atlasWords = (size_t)atlasSize * rowWords;
+    DevBuf maskBuf, offBuf, sizeBuf, areaBuf, orderBuf, atlasBuf, outBuf, itemBuf;
     if ((rc = maskBuf.alloc((size_t)total))) return rc;
     if ((rc = offBuf.alloc(8 * (size_t)chartCount))) return rc;
     if ((rc = sizeBuf.alloc(8 * (size_t)chartCount))) return rc;
     if ((rc = areaBuf.alloc(4 * (size_t)chartCount))) return rc;
     if ((rc = orderBuf.alloc(4 * (size_t)chartCount))) return rc;
-    if ((rc = atlasBuf.alloc(aBytes * (size_t)atlasCap))) return rc;
+    const size_t atlasBytes = asBits ? 8 * atlasWords * (size_t)atlasCap : aBytes * (size_t)atlasCap;
+    if ((rc = atlasBuf.alloc(atlasBytes))) return rc;
+    if (asBits && (rc = itemBuf.alloc(8 * atlasWords))) return rc;
     const size_t outInts = 3 * (size_t)chartCount + (size_t)atlasCap + 4;
     if ((rc = outBuf.alloc(4 * outInts))) return rc;
     PT_HIP(hipMemcpyAsync(maskBuf.p, masks, (size_t)total, hipMemcpyHostToDevice, st));
@@ -819,7 +969,7 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     PT_HIP(hipMemcpyAsync(sizeBuf.p, maskSizes, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(areaBuf.p, areas, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(orderBuf.p, order, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemsetAsync(atlasBuf.p, 0, aBytes * (size_t)atlasCap, st));
+    PT_HIP(hipMemsetAsync(atlasBuf.p, 0, atlasBytes, st));
     PT_HIP(hipMemsetAsync(outBuf.p, 0xff, 4 * outInts, st));            /* -1: not placed / no failure */
     AtlasArgs a;
     a.masks = (const uint8_t*)maskBuf.p; a.maskOffsets = (const int64_t*)offBuf.p; a.maskSizes = (const int32_t*)sizeBuf.p;
@@ -828,7 +978,12 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     int32_t* out = (int32_t*)outBuf.p;
     a.translations = out; a.atlasIndex = out + 2 * (size_t)chartCount; a.atlasCharts = out + 3 * (size_t)chartCount; a.status = a.atlasCharts + atlasCap;
     PT_HIP(hipMemsetAsync(a.atlasCharts, 0, 4 * (size_t)atlasCap, st));
-    k_atlas_place<<<1, kAtlasThreads, 0, st>>>(a);
+    if (asBits)
+    {
+        AtlasBitArgs g; g.a = a; g.atlasBits = (unsigned long long*)atlasBuf.p; g.itemBits = (unsigned long long*)itemBuf.p;
+        k_atlas_place_bits<<<1, kAtlasThreads, 0, st>>>(g);
+    }
+    else k_atlas_place<<<1, kAtlasThreads, 0, st>>>(a);
     PT_HIP(hipGetLastError());
     std::vector<int32_t> host(outInts);
     PT_HIP(hipMemcpyAsync(host.data(), out, 4 * outInts, hipMemcpyDeviceToHost, st));

@@ -57,9 +57,14 @@ def random_masks(n, lo, hi, seed, fill=0.8):
     return masks, offsets, sizes, areas
 
 
-@pytest.mark.parametrize("n,lo,hi,S,seed", [(300, 5, 14, 64, 1), (120, 8, 40, 128, 2), (2000, 5, 9, 96, 3), (40, 30, 90, 256, 4)])
-def test_atlas_place_matches_one_worker(n, lo, hi, S, seed):
+@pytest.mark.parametrize("form", ["bits", "bytes"])
+@pytest.mark.parametrize("n,lo,hi,S,seed", [(300, 5, 14, 64, 1), (120, 8, 40, 128, 2), (2000, 5, 9, 96, 3), (40, 30, 90, 256, 4), (60, 20, 400, 1024, 5), (30, 3, 150, 200, 6)])
+def test_atlas_place_matches_one_worker(n, lo, hi, S, seed, form, monkeypatch):
+    """both forms of the search: the atlas as bits in LDS (atlases up to 1024^2; charts whose bit rows fit LDS and, at 400 x 400,
+    one kept in HBM) and byte for byte in HBM (larger atlases)"""
     gpu_init()
+    if form == "bytes":
+        monkeypatch.setenv("PIMGPU_ATLAS_BYTES", "1")
     masks, offsets, sizes, areas = random_masks(n, lo, hi, seed)
     order = oracle_sort(areas)
     lib = load_oracle(True)
@@ -98,6 +103,9 @@ def test_atlas_place_reports_what_the_reference_spins_on():
         api.lightmap_atlas_place(big, np.zeros(1, np.int64), np.asarray([[32, 32]], np.int32), np.asarray([784.0], np.float32), np.zeros(1, np.int32), 32, 4)
     with pytest.raises(api.PimGpuError):
         api.lightmap_atlas_place(masks, offsets, sizes2, areas, np.zeros_like(order), 64, 2)       # not a permutation
+    odd = masks.copy(); odd[offsets[3] + 20] = 7
+    with pytest.raises(api.PimGpuError, match="neither 0 nor 0xff"):
+        api.lightmap_atlas_place(odd, offsets, sizes, areas, order, 64, 2)
     assert api.lightmap_atlas_place(masks[:0], offsets[:0], sizes[:0], areas[:0], order[:0], 64, 1)[2] == 0
 
 
