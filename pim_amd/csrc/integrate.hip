@@ -828,8 +828,7 @@ __global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restri
 
 /* CalcStdDev, render_system.c:1374-1394.  The reference accumulates mean and variance serially in fp32, in
  * pixel order, and that order is part of the result.  Per-pixel terms are computed in parallel (k_stddev_terms);
- * the two running sums are then formed by ONE lane in pixel order, the other 63 lanes of its wave only stage
- * the terms through LDS (k_stddev_sum). */
+ * the two running sums are then formed in pixel order by one wave (k_stddev_sum). */
 __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ color, int32_t len, const float* __restrict__ meanIn,
     float* __restrict__ terms)
 {
@@ -844,39 +843,44 @@ __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ 
     }
 }
 
-/* One wave.  The serial chain sum += term[k] is kept (its order is the result), but the running sum TRAVELS across the lanes
- * instead of the terms travelling to one lane: every lane holds one term of the current 64, and one DPP add per term,
- * acc[k] = acc[k - 1 (rotating)] + term[k], moves the true running sum from lane k - 1 to lane k (the other lanes compute
- * values nobody reads).  After 64 adds it sits in lane 63 and rotates into lane 0 for the next 64 terms.  One dependent
- * VALU instruction per term, no LDS, no cross-lane reads. */
-__global__ __launch_bounds__(64) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
+/*
+ * CalcStdDev's serial sums: sum += term[k] in pixel order, one dependent v_add_f32 per term -- the order is the result, so the
+ * chain cannot be split.  EVERY lane of the one wave runs the whole chain: the terms arrive by vector loads whose address is
+ * the same in all lanes (one 16-byte broadcast load brings four terms), kSumRing of them in flight -- a load is ~600 cycles
+ * away, the ring holds 768 cycles of additions -- so the adder does not wait for memory: 11.5 ms per sum at 1920 x 1080
+ * (5.5 ns per term).  Before: the running sum travelling across the lanes by one DPP add per term, 18.5 ms (the DPP wait
+ * states sit on the chain); before that one lane fed through LDS, 22 ms.  Same order of additions, same bits in all three.
+ * (Launched with 64 threads; the bound of 128 only keeps the compiler from proving the address uniform and moving the loads
+ * to the scalar unit, whose loads cannot be waited for one by one.)
+ */
+static constexpr int kSumRing = 48;
+__global__ __launch_bounds__(128) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
 {
-    constexpr int kWaveRor1 = 0x13C;                /* DPP control: wave rotate right by one lane (GFX9) */
-    const int lane = threadIdx.x;
+    const float4* __restrict__ t4 = (const float4*)terms + (threadIdx.x >> 6);       /* == terms: the launch has one wave */
+    const int32_t n4 = len >> 2;
     float acc = 0.0f;
-    float next = lane < len ? terms[lane] : 0.0f;
-    int32_t last = 0;                               /* lane that holds the total at the end */
-    for (int32_t base = 0; base < len; base += 64)
+    float4 ring[kSumRing];
+    int32_t i = 0;
+    if (n4 >= kSumRing)
     {
-        const float v = next;
-        const int32_t ahead = base + 64 + lane;
-        next = ahead < len ? terms[ahead] : 0.0f;
-        const int32_t m = min(64, len - base);
-        if (m == 64)
+#pragma unroll
+        for (int k = 0; k < kSumRing; ++k) ring[k] = t4[k];
+        for (; i + 2 * kSumRing <= n4; i += kSumRing)
         {
 #pragma unroll
-            for (int k = 0; k < 64; ++k)
-                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), kWaveRor1, 0xf, 0xf, false)) + v;
+            for (int k = 0; k < kSumRing; ++k)
+            {
+                const float4 v = ring[k];
+                ring[k] = t4[i + kSumRing + k];
+                acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+            }
         }
-        else
-        {
-            for (int k = 0; k < m; ++k)
-                acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), kWaveRor1, 0xf, 0xf, false)) + v;
-        }
-        last = m - 1;
+#pragma unroll
+        for (int k = 0; k < kSumRing; ++k) { const float4 v = ring[k]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
+        i += kSumRing;
     }
-    const float sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), last));
-    if (lane == 0) out[0] = sqrtOut ? pt_sqrt(sum) : sum;
+    for (int32_t j = i * 4; j < len; ++j) acc = acc + terms[j + (threadIdx.x >> 6)];
+    if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(acc) : acc;
 }
 
 /* ---------------------------------------------------------------------------------------------- */

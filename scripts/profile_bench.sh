@@ -12,6 +12,6 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
 done
 cd $R
 python3 scripts/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) 8 2 > $out/kernel_stats.txt
-python3 scripts/pmc_summary.py --min-grid 4096 $out/pmc_* > $out/pmc_summary.txt
+python3 scripts/pmc_summary.py --min-grid 4096 $out/pmc_* | grep -E "k_trace|k_shade|k_tail|k_init_image|k_resolve_image" > $out/pmc_summary.txt      # the kernels of the timed steps
 grep -h '"metric"' $out/kt.log | tail -1 > $out/bench_line.json
 echo done $wl
