@@ -48,8 +48,11 @@ struct TraceResources
 int32_t trace_stack_cap();
 
 /* trace.hip */
+/* targets (optional, per ray): >= 0 makes the ray a VISIBILITY query of that triangle -- hits[i] already holds the triangle's own
+ * record, the ray's tFar is its distance, and the launch only overwrites the record with a miss when something lies in front
+ * (trace.hip) */
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
-    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, const int32_t* targets = nullptr);
 int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, int32_t* occluded,
     int32_t n, hipStream_t stream);
 int make_rayhits(const DScene& scene, const float4* rayD, const DHit* hits, PimRayHit* out, int32_t n, hipStream_t stream);

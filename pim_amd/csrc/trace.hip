@@ -48,11 +48,19 @@ static constexpr int kTraceBlocksPerCU = 8;
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 1      /* waves per SIMD the kernel is compiled for at least (1: whatever its registers give, 6 at 73 VGPRs) */
 #endif
-template <bool ANY, bool COUNT>
+/*
+ * TGT: rays may name a TARGET triangle (targets[i] >= 0; the light-sampling rays of the integrator, whose question is "is the
+ * closest hit this triangle?", path_tracer.c:1813-1815).  The caller has tested the target itself with the same triangle test
+ * and left its record in hits[i] and its distance in the ray's tFar, so what remains is a visibility query: the walk ends at the
+ * first triangle the closest-hit rule would prefer -- nearer, or equally near with a lower id -- and the record is overwritten
+ * with a miss; if there is none the record stays as it is.  Bit for bit the answer of the full closest-hit walk followed by the
+ * comparison, without walking on once the outcome is known.
+ */
+template <bool ANY, bool COUNT, bool TGT = false>
 __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bvh, const float4* __restrict__ rayO, const float4* __restrict__ rayD,
     DHit* __restrict__ hits, int32_t* __restrict__ occluded, int32_t n, const int32_t* __restrict__ countDev,
     unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, unsigned long long* __restrict__ work,
-    uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk, int32_t stackCap)
+    uint32_t* __restrict__ chunkCounter, uint32_t* __restrict__ chunkCounterNext, int32_t dynChunk, int32_t stackCap, const int32_t* __restrict__ targets)
 {
     __shared__ unsigned long long sStack[PT_STACK_LDS * kTraceThreads];
     if (countDev) n = min(n, *countDev);
@@ -91,6 +99,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
     RaySlabQ sl = {};
     RayPre r = {};
     DHit h = {};
+    int32_t tgt = -1;
 
     for (;;)
     {
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                     const float4 o = rayO[mine], d = rayD[mine];
                     ri = mine;
                     h.prim = -1; h.t = d.w; h.u = 0.0f; h.v = 0.0f;
+                    if (TGT) tgt = targets[mine];
                     if (d.w > o.w)
                     {
                         r = ray_pre(o.x, o.y, o.z, d.x, d.y, d.z);
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                     }
                     else
                     {
-                        if (ANY) occluded[ri] = 0; else hits[ri] = h;
+                        if (ANY) occluded[ri] = 0; else hits[ri] = h;      /* no ray: a miss (also for a target the caller's own test missed) */
                         ri = -1;
                     }
                 }
@@ -215,9 +225,14 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                         if (tri_test_raw(r, p0, p1, p2, tNear, h.t, &t, &vn, &wn, &det))
                         {
                             const int32_t prim = __float_as_int(p0.w);
-                            if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim))) { h.prim = prim; h.t = t; h.u = vn; h.v = wn; hDet = det; }
+                            if (TGT && tgt >= 0)
+                            {
+                                /* t <= h.t = the target's own distance: anything but the target itself, or an equally near triangle with a higher id, is in front */
+                                if (prim != tgt && (t < h.t || prim < tgt)) { h.prim = -2; cur = PT_BVH_EMPTY; leaf = PT_BVH_EMPTY; st.init(); }
+                            }
+                            else if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim))) { h.prim = prim; h.t = t; h.u = vn; h.v = wn; hDet = det; }
                         }
-                        leaf = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
+                        if (!TGT || leaf != PT_BVH_EMPTY) leaf = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
                     }
                 }
             }
@@ -236,6 +251,10 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
         if (!active && ri >= 0)
         {
             if (ANY) occluded[ri] = h.prim >= 0 ? 1 : 0;
+            else if (TGT && tgt >= 0)
+            {
+                if (h.prim == -2) { h.prim = -1; h.u = 0.0f; h.v = 0.0f; hits[ri] = h; }      /* something in front: a miss; else the caller's record stands */
+            }
             else
             {
                 if (h.prim >= 0) { h.u = h.u / hDet; h.v = h.v / hDet; }
@@ -306,7 +325,7 @@ static int32_t trace_chunk(const DBvh& bvh)
  * completion signal.  Separate hipEventRecord calls around the launch put two barrier packets into the queue, ~6 us of
  * idle GPU each -- 12 per Cornell sample. */
 int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, const float4* rayD, DHit* hits,
-    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0, hipEvent_t t1)
+    int32_t n, const int32_t* countDev, hipStream_t stream, hipEvent_t t0, hipEvent_t t1, const int32_t* targets)
 {
     if (n <= 0) return PIMGPU_OK;
     int rc = res->ensure(); if (rc) return rc;
@@ -317,12 +336,19 @@ int trace_closest(const DBvh& bvh, TraceResources* res, const float4* rayO, cons
     if (res->counting)
     {
         if (t0) hipEventRecord(t0, stream);
-        k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
+        if (targets) k_trace<false, true, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
+        else k_trace<false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
         if (t1) hipEventRecord(t1, stream);
     }
-    else if (t0 && t1) hipExtLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
-        bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
-    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap);
+    else if (t0 && t1)
+    {
+        if (targets) hipExtLaunchKernelGGL((k_trace<false, false, true>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
+            bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
+        else hipExtLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kTraceThreads), 0, stream, t0, t1, 0,
+            bvh, rayO, rayD, hits, noOccluded, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
+    }
+    else if (targets) k_trace<false, false, true><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
+    else k_trace<false, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, hits, nullptr, n, countDev, res->spill, res->status, res->work, cc, cn, dc, cap, targets);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }
@@ -335,7 +361,7 @@ int trace_any(const DBvh& bvh, TraceResources* res, const float4* rayO, const fl
     const int blocks = (int)std::min<int64_t>(res->gridBlocks, ((int64_t)n + kTraceThreads - 1) / kTraceThreads);
     uint32_t* cc = res->status + 24 + res->chunkParity; uint32_t* cn = res->status + 24 + (res->chunkParity ^ 1); res->chunkParity ^= 1;
     const int32_t dc = trace_chunk(bvh), cap = trace_stack_cap();
-    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work, cc, cn, dc, cap);
+    k_trace<true, false><<<blocks, kTraceThreads, 0, stream>>>(bvh, rayO, rayD, nullptr, occluded, n, nullptr, res->spill, res->status, res->work, cc, cn, dc, cap, nullptr);
     PT_HIP(hipGetLastError());
     return PIMGPU_OK;
 }

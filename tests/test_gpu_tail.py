@@ -14,7 +14,7 @@ from tests.test_gpu_image import _render_both
 pytestmark = pytest.mark.gpu
 
 
-KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_DENSE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS")
+KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_DENSE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS", "PIMGPU_NEE_TARGET")
 
 
 @pytest.fixture
@@ -103,3 +103,19 @@ def test_both_builds_of_the_tail_kernel_bit_exact(tail_env, dense):
     _render_both(scenes.cornell_box(), 128, 72, 2, 8)
     sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
     _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
+
+
+@pytest.mark.parametrize("targeted", ["0", "1"])
+def test_light_rays_as_visibility_queries_bit_exact(tail_env, targeted):
+    """the wavefront's light-sampling rays run as plain closest-hit queries or as visibility queries of their light
+    (k_trace TGT, picked by the size of the tree): either way the oracle's bits and ray counts, with occluders in front of
+    the lights (spheres), media in-scatter rays and a sky"""
+    os.environ["PIMGPU_NEE_TARGET"] = targeted
+    os.environ["PIMGPU_TAIL_BOUNCE"] = "-1"
+    _render_both(scenes.cornell_box(), 128, 72, 3, 8)
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    _render_both(sc, 80, 45, 2, 6, cam=scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0)))
+    _render_both(scenes.cornell_box(media=scenes.foggy_media(6.0)), 64, 36, 2, 5)
+    os.environ["PIMGPU_TAIL_BOUNCE"] = "2"
+    sc = scenes.synthetic_scene(target_tris=20000, seed=5, extent=30.0, emissive_attempts=32)
+    _render_both(sc, 96, 54, 2, 6, cam=scenes.synthetic_camera(30.0))
