@@ -808,6 +808,38 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
             if (pos >= count) break;
             slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true;
         }
+#ifdef PT_TAIL_PROF
+        TraverseCounts tc0 = { 0u, 0u }, tc1 = { 0u, 0u };
+        const long long c0 = wall_clock64();
+        const DHit eh = traverse<false, LdsStack, true>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, &tc0);
+        const long long c1 = wall_clock64();
+        ++ext;
+        const StageAOut ra = stage_a<true, false>(s, a, slot, eh, b, st);
+        shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
+        const long long c2 = wall_clock64();
+        DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
+        if (ra.nD.w > ra.nO.w) nh = traverse<false, LdsStack, true>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow, &tc1);
+        const long long c3 = wall_clock64();
+        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
+        other += rb.other; overflow |= rb.overflow;
+        const long long c4 = wall_clock64();
+        {
+            /* per wave-bounce: time of the four phases; steps of the rays: sum over lanes, max over lanes, lanes */
+            uint32_t s0 = tc0.nodes + tc0.tris, s1 = tc1.nodes + tc1.tris;
+            uint32_t m0 = s0, m1 = s1;
+            const uint64_t act = __ballot(true);
+            for (int off = 32; off; off >>= 1) { m0 = max(m0, (uint32_t)__shfl_xor((int)m0, off, 64)); m1 = max(m1, (uint32_t)__shfl_xor((int)m1, off, 64)); }
+            atomicAdd(&a.stats[16], (unsigned long long)s0); atomicAdd(&a.stats[17], (unsigned long long)s1);
+            const int leader = __ffsll((long long)act) - 1;
+            if ((int)(threadIdx.x & 63) == leader)
+            {
+                atomicAdd(&a.stats[8], (unsigned long long)(c1 - c0)); atomicAdd(&a.stats[9], (unsigned long long)(c2 - c1));
+                atomicAdd(&a.stats[10], (unsigned long long)(c3 - c2)); atomicAdd(&a.stats[11], (unsigned long long)(c4 - c3));
+                atomicAdd(&a.stats[12], 1ull); atomicAdd(&a.stats[13], (unsigned long long)__popcll(act));
+                atomicAdd(&a.stats[14], (unsigned long long)m0); atomicAdd(&a.stats[15], (unsigned long long)m1);
+            }
+        }
+#else
         const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
         ++ext;
         const StageAOut ra = stage_a<true, false>(s, a, slot, eh, b, st);
@@ -816,6 +848,7 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
         if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
         const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
         other += rb.other; overflow |= rb.overflow;
+#endif
         have = rb.alive;
         o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
         d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
@@ -1017,7 +1050,11 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     { int rcT = g.trace->ensure(); if (rcT) return rcT; }      /* the spill area behind the kernels' traversal stacks: gridBlocks * 256 lanes */
     int32_t init[64] = {}; init[0] = n;
     PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
+#ifdef PT_TAIL_PROF
+    PT_HIP(hipMemsetAsync(g.stats, 0, 256, st));
+#else
     PT_HIP(hipMemsetAsync(g.stats, 0, 64, st));
+#endif
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1095,7 +1132,16 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
      * the next intersect call */
     uint32_t traceStatus = 0;
     PT_HIP(hipMemcpyAsync(&traceStatus, g.trace->status, sizeof(traceStatus), hipMemcpyDeviceToHost, st));
+#ifdef PT_TAIL_PROF
+    unsigned long long prof[10];
+    PT_HIP(hipMemcpyAsync(prof, g.stats + 8, sizeof(prof), hipMemcpyDeviceToHost, st));
+#endif
     PT_HIP(hipStreamSynchronize(st));
+#ifdef PT_TAIL_PROF
+    if (prof[4]) fprintf(stderr, "tailprof wave-bounces %llu lanes/wb %.1f | us per wave-bounce: ext %.1f stageA %.1f nee %.1f stageB %.1f | ext steps mean %.1f max-in-wave %.1f | nee steps mean %.1f max-in-wave %.1f\n",
+        prof[4], (double)prof[5] / prof[4], prof[0] * 0.01 / prof[4], prof[1] * 0.01 / prof[4], prof[2] * 0.01 / prof[4], prof[3] * 0.01 / prof[4],
+        (double)prof[8] / prof[5], (double)prof[6] / prof[4], (double)prof[9] / prof[5], (double)prof[7] / prof[4]);
+#endif
     if (traceStatus & 1u) { PT_HIP(hipMemsetAsync(g.trace->status, 0, 4, st)); hs[4] |= 1ull; }
     float clsMs[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; int32_t traceLaunches = 0;
     for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.t0, e.t1); clsMs[e.cls] += ms; if (e.cls == 0) ++traceLaunches; }

@@ -185,6 +185,8 @@ __device__ __forceinline__ bool tri_test_raw(const RayPre& r, float4 p0, float4 
     return true;
 }
 
+__device__ __forceinline__ float4 as_f4(uint4 w) { return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)); }
+
 __device__ __forceinline__ void hit_consider(DHit& h, int32_t prim, float t, float u, float v)
 {
     if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim)))
@@ -282,6 +284,15 @@ struct LdsStack
 /* per-lane work counters of the measurement build (COUNT = true): nodes fetched (64 B each, the compressed copy), triangles tested (48 B each) */
 struct TraverseCounts { uint32_t nodes, tris; };
 
+/*
+ * One memory round trip per step, whatever the lane is at.  The callers of this function (the tail kernel, the stages'
+ * inline rays, set-up) are latency chains: a wave's lanes sit at inner nodes and at leaves at the same time, and a loop
+ * with a node branch and a leaf branch pays the two branches' load latencies one after the other on every trip (measured
+ * in k_tail: 2.5 us per step on the 1 M-triangle scene).  Here a step loads 64 bytes from ONE address -- the compressed node,
+ * or the leaf's first triangle and the first vertex of its second -- plus the rest of a second triangle under a
+ * predicate, all issued before any of it is used; the node arithmetic and the triangle tests then run on registers.
+ * (A leaf's last triangle may be the last of the array: the builder pads tris[] by one triangle.)
+ */
 template <bool ANY, class Stack, bool COUNT = false>
 __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, float oz, float dx, float dy, float dz,
     float tNear, float tFar, Stack& st, bool& overflow, TraverseCounts* counts = nullptr)
@@ -294,15 +305,21 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
     const uint4* __restrict__ cnodes = bvh.cnodes;
     const RaySlabQ sl = ray_slab_q(ox, oy, oz, dx, dy, dz, bvh.nodes[7].x);
     const bool px = sl.ix >= 0.0f, py = sl.iy >= 0.0f, pz = sl.iz >= 0.0f;
-    const float4* __restrict__ tris = bvh.tris;
+    const uint4* __restrict__ tris = (const uint4*)bvh.tris;
     for (;;)
     {
-        if (cur >= 0)
+        const bool inner = cur >= 0;
+        const uint32_t code = (uint32_t)~cur;
+        const uint32_t first = code >> 3, cnt = inner ? 0u : (code & 7u) + 1u;
+        const uint4* q = inner ? cnodes + (size_t)cur * 4 : tris + (size_t)first * 3;
+        const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+        uint4 w4 = make_uint4(0u, 0u, 0u, 0u), w5 = w4;
+        if (cnt > 1u) { w4 = q[4]; w5 = q[5]; }
+        int32_t next = PT_BVH_EMPTY;
+        if (inner)
         {
             if (COUNT) counts->nodes++;
             /* the 64-byte compressed node (pt_device.h), decoded as in the batched kernel (trace.hip) */
-            const uint4* q = cnodes + (size_t)cur * 4;
-            const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
             float d[4]; int32_t c[4];
             c[0] = (int32_t)w3.x; c[1] = (int32_t)w3.y; c[2] = (int32_t)w3.z; c[3] = (int32_t)w3.w;
             const float ax = __uint_as_float(w0.w) * sl.ix, ay = __uint_as_float(w2.z) * sl.iy, az = __uint_as_float(w2.w) * sl.iz;
@@ -331,34 +348,48 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
             if (d[3] < __builtin_inff()) overflow |= !st.push(d[3], c[3]);
             if (d[2] < __builtin_inff()) overflow |= !st.push(d[2], c[2]);
             if (d[1] < __builtin_inff()) overflow |= !st.push(d[1], c[1]);
-            if (d[0] < __builtin_inff()) { cur = c[0]; continue; }
+            if (d[0] < __builtin_inff()) next = c[0];
         }
         else
         {
-            const uint32_t code = (uint32_t)~cur;
-            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; ++k)
+            if (COUNT) counts->tris += cnt;
+            float t, u, v;
+            if (tri_test(r, as_f4(w0), as_f4(w1), as_f4(w2), tNear, h.t, &t, &u, &v))
             {
-                if (COUNT) counts->tris++;
-                const float4* tp = tris + (size_t)(first + k) * 3;
-                const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
-                float t, u, v;
-                if (tri_test(r, p0, p1, p2, tNear, h.t, &t, &u, &v))
+                hit_consider(h, (int32_t)w0.w, t, u, v);
+                if (ANY) return h;
+            }
+            if (cnt > 1u && tri_test(r, as_f4(w3), as_f4(w4), as_f4(w5), tNear, h.t, &t, &u, &v))
+            {
+                hit_consider(h, (int32_t)w3.w, t, u, v);
+                if (ANY) return h;
+            }
+#if PT_LEAF_MAX > 2
+            for (uint32_t k = 2; k < cnt; ++k)
+            {
+                const uint4* tp = tris + (size_t)(first + k) * 3;
+                const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                if (tri_test(r, as_f4(p0), as_f4(p1), as_f4(p2), tNear, h.t, &t, &u, &v))
                 {
-                    hit_consider(h, __float_as_int(p0.w), t, u, v);
+                    hit_consider(h, (int32_t)p0.w, t, u, v);
                     if (ANY) return h;
                 }
             }
+#endif
         }
-        /* pop, culling entries that start beyond the current closest hit */
-        float t; int32_t c;
-        bool got = false;
-        while (st.pop(&t, &c))
+        if (next == PT_BVH_EMPTY)
         {
-            if (t <= h.t) { got = true; break; }
+            /* pop, culling entries that start beyond the current closest hit */
+            float t; int32_t c;
+            bool got = false;
+            while (st.pop(&t, &c))
+            {
+                if (t <= h.t) { got = true; break; }
+            }
+            if (!got) break;
+            next = c;
         }
-        if (!got) break;
-        cur = c;
+        cur = next;
     }
     return h;
 }
