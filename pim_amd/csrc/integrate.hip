@@ -974,21 +974,24 @@ int stddev_scratch_setup(int device)
  * header), so a stale history is harmless; PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
  */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 6));      /* tuning knobs, not API */
-static const int kTailMaxPaths = std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 350000));
-static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /* 0: 8 or 16 with the build below */
-/* Two builds of k_tail: 208 VGPRs (2 waves per SIMD) and <= 128 VGPRs with spills (4 per SIMD).  A tree that lives in L2
- * leaves little latency to hide and the spills cost more than the extra waves give (Cornell 2.22 against 2.29 ms); a
- * tree served from the Infinity Cache is the other way round (1 M triangles 7.52 against 7.13 ms).  The host picks by
- * the size of the tree. */
+static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 2));      /* tuning knobs, not API */
+static const int kTailMaxPaths = std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 1500000));
+static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /* 0: 12 or 16 with the build below */
+/* Two builds of k_tail: 168 VGPRs (3 waves per SIMD, 76 B of spills) and <= 128 VGPRs with more spills (4 per SIMD).  A
+ * tree that lives in L2 leaves little latency to hide and the spills cost more than the extra waves give; a tree served
+ * from the Infinity Cache is the other way round (Cornell 1080p: tail 0.93 ms at 3 waves, 1.01 at 2 or 4, 1.28 at 5;
+ * 1 M triangles: 3.42 / 3.10 / 3.13 ms at 3 / 4 / 5).  The host picks by the size of the tree. */
 static constexpr int64_t kTailDenseTreeBytes = 8ll << 20;
 
 static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
     if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
     if (g.historyN != n || g.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
-    /* ... and in absolute terms no more than about what the machine holds at k_tail's occupancy: beyond that the tail is
-     * no longer latency-bound and its one-lane-per-path rays cost several times the batched ones (4K: 16.6 -> ms with n / 6) */
+    /* ... and in absolute terms no more than about 1.5 M paths, a few times what the machine holds at k_tail's occupancy
+     * (its lanes take further paths as theirs end): per path-bounce the tail costs about 1.4 x the batched launches, which
+     * pays as long as the wavefront's launches sit near their latency floors.  Swept after the inline traversal went to
+     * one round trip per step (1 M triangles: switch at bounce 1 / 2 / 3 -> 5.96 / 6.43 / 6.9 ms at 1080p, 16.1 / 14.9 /
+     * 15.2 ms at 4K; Cornell 1080p 2.10 / 2.19) */
     const int64_t threshold = std::min<int64_t>((int64_t)n / kTailFraction, kTailMaxPaths);
     for (int32_t b = 1; b < g.historyBounces && b < bounceLimit; ++b)
         if ((int64_t)g.history[b] < threshold) return b;
@@ -1091,12 +1094,12 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
             const int64_t treeBytes = 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount;
             const int forceDense = env_int("PIMGPU_TAIL_DENSE", -1);            /* -1: by tree size; 0 / 1 force (tests) */
             const bool dense = forceDense >= 0 ? forceDense != 0 : treeBytes > kTailDenseTreeBytes;
-            const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 8);
+            const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 12);
             const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * wavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
             const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
             timed(3);
             if (dense) PT_LAUNCH(k_tail<4>, tailBlocks, kTailThreads, scene->d, a);
-            else PT_LAUNCH(k_tail<1>, tailBlocks, kTailThreads, scene->d, a);
+            else PT_LAUNCH(k_tail<3>, tailBlocks, kTailThreads, scene->d, a);
             g.tailBounce = b;
             if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
             break;
