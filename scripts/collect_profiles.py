@@ -13,8 +13,13 @@ for wl in sys.argv[2:]:
     # the batched k_trace<closest> launches: the group (kernel, grid) with the most launches among the full-size grids
     groups = {}
     for line in open(os.path.join(src, "pmc_summary.txt")):
-        m = re.match(r"void pt::k_trace<false, false>\s+grid\s+(\d+)\s+(\S+)\s+launches\s+(\d+)\s+mean\s+([\d.]+)", line)
-        if m: groups.setdefault(int(m.group(1)), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
+        # closest-hit builds: plain and with target triangles (TGT, the light-sampling rays on large trees) -- one population
+        m = re.match(r"void pt::k_trace<false, false(?:, (?:false|true))?>\s+grid\s+(\d+)\s+(\S+)\s+launches\s+(\d+)\s+mean\s+([\d.]+)", line)
+        if m:
+            n0, s0 = groups.setdefault(int(m.group(1)), {}).get(m.group(2), (0, 0.0))
+            groups[int(m.group(1))][m.group(2)] = (n0 + int(m.group(3)), s0 + int(m.group(3)) * float(m.group(4)))
+    for g in groups.values():
+        for k, (n0, s0) in list(g.items()): g[k] = (n0, s0 / n0)
     grid = max(groups, key=lambda g: (groups[g].get("FETCH_SIZE", (0, 0))[0], g))
     vals = {k: v[1] for k, v in groups[grid].items()}
     launches = groups[grid]["FETCH_SIZE"][0]
