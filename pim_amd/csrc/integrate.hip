@@ -799,60 +799,68 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
     st.spillStride = (int64_t)gridDim.x * kTailThreads;
     st.spill = (glb_u64*)(a.spill + ((int64_t)blockIdx.x * kTailThreads + threadIdx.x));
     st.cap = a.stackCap;
+    /* the two rays of a bounce are walked by the whole wave (traverse_coop): lanes without a path stay in the loop as helpers */
+    __shared__ unsigned long long sCoop[2 * kTailThreads];
+    __shared__ int sList[kTailThreads];
+    CoopArea ca;
+    ca.best = (lds_u64*)sCoop; ca.uv = (lds_u64*)(sCoop + kTailThreads); ca.list = (lds_i32*)sList;
+    bool drained = (int32_t)(threadIdx.x & 63) >= a.tailLanes;
     for (;;)
     {
-        if ((int32_t)(threadIdx.x & 63) >= a.tailLanes) break;
-        const int32_t pos = wave_append(&a.counters[4], !have);
-        if (!have)
+        const bool want = !have && !drained;
+        const int32_t pos = wave_append(&a.counters[4], want);
+        if (want)
         {
-            if (pos >= count) break;
-            slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true;
+            if (pos >= count) drained = true;
+            else { slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true; }
         }
+        if (__ballot(have) == 0ull) break;
 #ifdef PT_TAIL_PROF
         TraverseCounts tc0 = { 0u, 0u }, tc1 = { 0u, 0u };
         const long long c0 = wall_clock64();
-        const DHit eh = traverse<false, LdsStack, true>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, &tc0);
+        const DHit eh = traverse_coop<true>(s.bvh, have, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, ca, &tc0);
         const long long c1 = wall_clock64();
-        ++ext;
-        const StageAOut ra = stage_a<true, false>(s, a, slot, eh, b, st);
-        shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
-        const long long c2 = wall_clock64();
-        DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
-        if (ra.nD.w > ra.nO.w) nh = traverse<false, LdsStack, true>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow, &tc1);
-        const long long c3 = wall_clock64();
-        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
-        other += rb.other; overflow |= rb.overflow;
-        const long long c4 = wall_clock64();
+#else
+        const DHit eh = traverse_coop(s.bvh, have, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow, ca);
+#endif
+        StageAOut ra; ra.nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ra.nD = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
+        if (have)
         {
-            /* per wave-bounce: time of the four phases; steps of the rays: sum over lanes, max over lanes, lanes */
-            uint32_t s0 = tc0.nodes + tc0.tris, s1 = tc1.nodes + tc1.tris;
-            uint32_t m0 = s0, m1 = s1;
+            ++ext;
+            ra = stage_a<true, false>(s, a, slot, eh, b, st);
+            shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
+        }
+#ifdef PT_TAIL_PROF
+        const long long c2 = wall_clock64();
+        DHit nh = traverse_coop<true>(s.bvh, have, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow, ca, &tc1);
+        const long long c3 = wall_clock64();
+#else
+        DHit nh = traverse_coop(s.bvh, have, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow, ca);
+#endif
+        if (have)
+        {
+            const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
+            other += rb.other; overflow |= rb.overflow;
+            have = rb.alive;
+            o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
+            d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
+            ++b;
+        }
+#ifdef PT_TAIL_PROF
+        {
+            /* per wave-bounce: time of the four phases; trips of the wave's walks (lane 0), triangles tested */
+            const long long c4 = wall_clock64();
             const uint64_t act = __ballot(true);
-            for (int off = 32; off; off >>= 1) { m0 = max(m0, (uint32_t)__shfl_xor((int)m0, off, 64)); m1 = max(m1, (uint32_t)__shfl_xor((int)m1, off, 64)); }
-            atomicAdd(&a.stats[16], (unsigned long long)s0); atomicAdd(&a.stats[17], (unsigned long long)s1);
-            const int leader = __ffsll((long long)act) - 1;
-            if ((int)(threadIdx.x & 63) == leader)
+            atomicAdd(&a.stats[16], (unsigned long long)tc0.tris); atomicAdd(&a.stats[17], (unsigned long long)tc1.tris);
+            if ((threadIdx.x & 63) == 0)
             {
                 atomicAdd(&a.stats[8], (unsigned long long)(c1 - c0)); atomicAdd(&a.stats[9], (unsigned long long)(c2 - c1));
                 atomicAdd(&a.stats[10], (unsigned long long)(c3 - c2)); atomicAdd(&a.stats[11], (unsigned long long)(c4 - c3));
                 atomicAdd(&a.stats[12], 1ull); atomicAdd(&a.stats[13], (unsigned long long)__popcll(act));
-                atomicAdd(&a.stats[14], (unsigned long long)m0); atomicAdd(&a.stats[15], (unsigned long long)m1);
+                atomicAdd(&a.stats[14], (unsigned long long)tc0.nodes); atomicAdd(&a.stats[15], (unsigned long long)tc1.nodes);
             }
         }
-#else
-        const DHit eh = traverse<false>(s.bvh, o.x, o.y, o.z, d.x, d.y, d.z, o.w, d.w, st, overflow);
-        ++ext;
-        const StageAOut ra = stage_a<true, false>(s, a, slot, eh, b, st);
-        shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
-        DHit nh; nh.prim = -1; nh.t = ra.nD.w; nh.u = 0.0f; nh.v = 0.0f;
-        if (ra.nD.w > ra.nO.w) nh = traverse<false>(s.bvh, ra.nO.x, ra.nO.y, ra.nO.z, ra.nD.x, ra.nD.y, ra.nD.z, ra.nO.w, ra.nD.w, st, overflow);
-        const StageBOut rb = stage_b<true>(s, a, slot, eh, ra.nD, nh, b, st);
-        other += rb.other; overflow |= rb.overflow;
 #endif
-        have = rb.alive;
-        o = make_float4(rb.ro.x, rb.ro.y, rb.ro.z, 0.0f);
-        d = make_float4(rb.rd.x, rb.rd.y, rb.rd.z, PT_RCP_EPS);
-        ++b;
     }
     __shared__ int32_t sh[2 + kTailThreads / 64];
     block_add(&a.stats[0], ext, sh);
@@ -1141,9 +1149,9 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
 #endif
     PT_HIP(hipStreamSynchronize(st));
 #ifdef PT_TAIL_PROF
-    if (prof[4]) fprintf(stderr, "tailprof wave-bounces %llu lanes/wb %.1f | us per wave-bounce: ext %.1f stageA %.1f nee %.1f stageB %.1f | ext steps mean %.1f max-in-wave %.1f | nee steps mean %.1f max-in-wave %.1f\n",
-        prof[4], (double)prof[5] / prof[4], prof[0] * 0.01 / prof[4], prof[1] * 0.01 / prof[4], prof[2] * 0.01 / prof[4], prof[3] * 0.01 / prof[4],
-        (double)prof[8] / prof[5], (double)prof[6] / prof[4], (double)prof[9] / prof[5], (double)prof[7] / prof[4]);
+    if (prof[4]) fprintf(stderr, "tailprof wave-bounces %llu | us per wave-bounce: ext %.1f stageA %.1f nee %.1f stageB %.1f | trips of the wave per walk: ext %.1f nee %.1f\n",
+        prof[4], prof[0] * 0.01 / prof[4], prof[1] * 0.01 / prof[4], prof[2] * 0.01 / prof[4], prof[3] * 0.01 / prof[4],
+        (double)prof[6] / prof[4], (double)prof[7] / prof[4]);
 #endif
     if (traceStatus & 1u) { PT_HIP(hipMemsetAsync(g.trace->status, 0, 4, st)); hs[4] |= 1ull; }
     float clsMs[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; int32_t traceLaunches = 0;

@@ -252,6 +252,12 @@ struct LdsStack
         *t = __uint_as_float((uint32_t)v); *c = (int32_t)(v >> 32);
         return true;
     }
+    /* pop that stops at `base`: the entries below it have been handed to other lanes (traverse_coop) */
+    __device__ __forceinline__ bool popb(int base, float* t, int32_t* c)
+    {
+        if (sp <= base) return false;
+        return pop(t, c);
+    }
     /* up to three entries, farthest first, d1 <= d2 <= d3 with misses (+inf) last; the common case (all of them fit
      * the LDS part) is three predicated 64-bit LDS stores without a branch per entry */
     __device__ __forceinline__ bool push3(float d1, int32_t c1, float d2, int32_t c2, float d3, int32_t c3)
@@ -390,6 +396,190 @@ __device__ __forceinline__ DHit traverse(const DBvh& bvh, float ox, float oy, fl
             next = c;
         }
         cur = next;
+    }
+    return h;
+}
+
+
+/*
+ * The same walk, shared by the lanes of a wave.  Called by every lane of the (converged) wave, with or without a ray of its
+ * own (valid = false: a helper).  A wave that runs one ray per lane in lock-step takes as many steps as its LONGEST ray
+ * (measured in k_tail: 85 against a mean of 43, with 35 of 64 lanes holding a ray at all), and every step costs the whole
+ * wave its instructions.  Here a lane that has run out of work takes the BOTTOM entry of a busy lane's stack -- the ray
+ * travels by cross-lane reads, the entry through LDS -- and walks that subtree for the ray's owner.  The closest hit of a ray
+ * is kept per OWNER in LDS as one 64-bit key (t bits, prim): an atomic minimum on it IS the closest-hit rule of the contract
+ * (smaller t, then smaller prim; t > 0, so the float bits order as integers), every lane that works for the owner culls
+ * against it, and the lane whose key stands after the minimum writes its barycentrics next to it.  Which lane meets which
+ * triangle changes nothing of the result (contract), so this returns the bits of traverse<false>.
+ */
+typedef __attribute__((address_space(3))) int lds_i32;
+struct CoopArea
+{
+    lds_u64* best;      /* [64] per owner lane: (t bits << 32) | prim, prim = 0x7fffffff: no hit yet, t = tFar */
+    lds_u64* uv;        /* [64] per owner lane: (v bits << 32) | u bits of the hit in `best` */
+    lds_i32* list;      /* [64] scratch: lanes that can give work away */
+};
+#ifndef PT_COOP_LEAF_VOTE
+#define PT_COOP_LEAF_VOTE 16
+#endif
+#ifndef PT_STEAL_MIN
+#define PT_STEAL_MIN 8      /* lanes out of work before the wave spends a trip on handing work over */
+#endif
+
+__device__ __forceinline__ int wave_rank(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+template <bool COUNT = false>
+__device__ __forceinline__ DHit traverse_coop(const DBvh& bvh, bool valid, float ox, float oy, float oz, float dx, float dy, float dz,
+    float tNear, float tFar, LdsStack& st, bool& overflow, const CoopArea& ca, TraverseCounts* counts = nullptr)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    valid = valid && tFar > tNear;
+    RayPre r = {}; RaySlabQ sl = {};
+    if (valid) { r = ray_pre(ox, oy, oz, dx, dy, dz); sl = ray_slab_q(ox, oy, oz, dx, dy, dz, bvh.nodes[7].x); }
+    int owner = lane, base = 0;
+    st.init();
+    ca.best[lane] = ((unsigned long long)__float_as_uint(tFar) << 32) | 0x7fffffffull;
+    int32_t cur = valid ? 0 : PT_BVH_EMPTY;
+    const uint4* __restrict__ cnodes = bvh.cnodes;
+    const uint4* __restrict__ tris = (const uint4*)bvh.tris;
+    for (;;)
+    {
+        const unsigned long long all = __ballot(true);
+        const unsigned long long idle = __ballot(cur == PT_BVH_EMPTY);
+        if (idle == all) break;
+        if (COUNT && lane == 0) counts->nodes++;          /* measurement build: trips of the wave (lane 0 is always in the call) */
+        if ((int)__popcll(idle) >= PT_STEAL_MIN)
+        {
+            const bool giver = cur != PT_BVH_EMPTY && base < (st.sp < PT_STACK_LDS ? st.sp : PT_STACK_LDS);
+            const unsigned long long givers = __ballot(giver);
+            if (givers != 0ull)
+            {
+                /* taker i takes entry (i / givers) from the bottom of giver (i mod givers), while that giver has one */
+                const int nGivers = (int)__popcll(givers), nIdle = (int)__popcll(idle);
+                const int rankG = wave_rank(givers), rankI = wave_rank(idle);
+                if (giver) ca.list[rankG] = lane;
+                __builtin_amdgcn_wave_barrier();
+                const bool asks = cur == PT_BVH_EMPTY;
+                const int from = asks ? ca.list[rankI % nGivers] : lane;
+                const int depth = rankI / nGivers;
+                const int avail = giver ? (st.sp < PT_STACK_LDS ? st.sp : PT_STACK_LDS) - base : 0;
+                /* the giver's ray, as it has prepared it, its owner and the bottom of its stack */
+                const int fkx = __shfl(r.kx, from, 64), fky = __shfl(r.ky, from, 64), fkz = __shfl(r.kz, from, 64);
+                const float fSx = __shfl(r.Sx, from, 64), fSy = __shfl(r.Sy, from, 64), fSz = __shfl(r.Sz, from, 64);
+                const float fox = __shfl(r.ox, from, 64), foy = __shfl(r.oy, from, 64), foz = __shfl(r.oz, from, 64);
+                const float fix = __shfl(sl.ix, from, 64), fiy = __shfl(sl.iy, from, 64), fiz = __shfl(sl.iz, from, 64);
+                const float fnx = __shfl(sl.nx, from, 64), fny = __shfl(sl.ny, from, 64), fnz = __shfl(sl.nz, from, 64);
+                const float ffx = __shfl(sl.fx, from, 64), ffy = __shfl(sl.fy, from, 64), ffz = __shfl(sl.fz, from, 64);
+                const float fNear = __shfl(tNear, from, 64);
+                const int fOwner = __shfl(owner, from, 64), fBase = __shfl(base, from, 64), fAvail = __shfl(avail, from, 64);
+                if (asks && depth < fAvail)
+                {
+                    const unsigned long long e = st.lds[(fBase + depth) * st.ldsStride + (from - lane)];
+                    r.kx = fkx; r.ky = fky; r.kz = fkz; r.Sx = fSx; r.Sy = fSy; r.Sz = fSz; r.ox = fox; r.oy = foy; r.oz = foz;
+                    sl.ix = fix; sl.iy = fiy; sl.iz = fiz; sl.nx = fnx; sl.ny = fny; sl.nz = fnz; sl.fx = ffx; sl.fy = ffy; sl.fz = ffz;
+                    tNear = fNear; owner = fOwner;
+                    cur = (int32_t)(e >> 32);
+                }
+                if (giver)
+                {
+                    const int askers = rankG < nIdle ? (nIdle - rankG + nGivers - 1) / nGivers : 0;      /* idle lanes i with i mod givers == rankG */
+                    base += askers < avail ? askers : avail;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#if PT_COOP_LEAF_VOTE > 0
+        /* leaves wait until enough lanes stand at one (or no lane has a node): the triangle code costs the whole wave its
+         * instructions on every trip it runs */
+        const unsigned long long atLeaf = __ballot(cur < 0 && cur != PT_BVH_EMPTY);
+        const bool leafTrip = (int)__popcll(atLeaf) >= PT_COOP_LEAF_VOTE || __ballot(cur >= 0) == 0ull;
+        if (cur != PT_BVH_EMPTY && (cur >= 0 || leafTrip))
+#else
+        if (cur != PT_BVH_EMPTY)
+#endif
+        {
+            const bool px = sl.ix >= 0.0f, py = sl.iy >= 0.0f, pz = sl.iz >= 0.0f;
+            const bool inner = cur >= 0;
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, cnt = inner ? 0u : (code & 7u) + 1u;
+            const uint4* q = inner ? cnodes + (size_t)cur * 4 : tris + (size_t)first * 3;
+            const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+            uint4 w4 = make_uint4(0u, 0u, 0u, 0u), w5 = w4;
+            if (cnt > 1u) { w4 = q[4]; w5 = q[5]; }
+            const float lim = __uint_as_float((uint32_t)(ca.best[owner] >> 32));        /* the owner's closest hit so far, whoever found it */
+            int32_t next = PT_BVH_EMPTY;
+            if (inner)
+            {
+                float d[4]; int32_t c[4];
+                c[0] = (int32_t)w3.x; c[1] = (int32_t)w3.y; c[2] = (int32_t)w3.z; c[3] = (int32_t)w3.w;
+                const float ax = __uint_as_float(w0.w) * sl.ix, ay = __uint_as_float(w2.z) * sl.iy, az = __uint_as_float(w2.w) * sl.iz;
+                const float bnx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.nx), bfx = __builtin_fmaf(__uint_as_float(w0.x), sl.ix, sl.fx);
+                const float bny = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.ny), bfy = __builtin_fmaf(__uint_as_float(w0.y), sl.iy, sl.fy);
+                const float bnz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.nz), bfz = __builtin_fmaf(__uint_as_float(w0.z), sl.iz, sl.fz);
+                const uint32_t qnx = px ? w1.x : w1.w, qfx = px ? w1.w : w1.x;
+                const uint32_t qny = py ? w1.y : w2.x, qfy = py ? w2.x : w1.y;
+                const uint32_t qnz = pz ? w1.z : w2.y, qfz = pz ? w2.y : w1.z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const float tnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 255u), ax, bnx), tfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 255u), ax, bfx);
+                    const float tny = __builtin_fmaf((float)((qny >> (8 * k)) & 255u), ay, bny), tfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 255u), ay, bfy);
+                    const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 255u), az, bnz), tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 255u), az, bfz);
+                    const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tNear));
+                    const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, lim));
+                    d[k] = (t0 <= t1 && c[k] != PT_BVH_EMPTY) ? t0 : __builtin_inff();
+                }
+                PT_SWAP_IF(d[0], c[0], d[1], c[1]);
+                PT_SWAP_IF(d[2], c[2], d[3], c[3]);
+                PT_SWAP_IF(d[0], c[0], d[2], c[2]);
+                PT_SWAP_IF(d[1], c[1], d[3], c[3]);
+                PT_SWAP_IF(d[1], c[1], d[2], c[2]);
+                if (d[3] < __builtin_inff()) overflow |= !st.push(d[3], c[3]);
+                if (d[2] < __builtin_inff()) overflow |= !st.push(d[2], c[2]);
+                if (d[1] < __builtin_inff()) overflow |= !st.push(d[1], c[1]);
+                if (d[0] < __builtin_inff()) next = c[0];
+            }
+            else
+            {
+                if (COUNT) counts->tris += cnt;
+                DHit h; h.prim = -1; h.t = lim; h.u = 0.0f; h.v = 0.0f;
+                float t, u, v;
+                if (tri_test(r, as_f4(w0), as_f4(w1), as_f4(w2), tNear, h.t, &t, &u, &v)) hit_consider(h, (int32_t)w0.w, t, u, v);
+                if (cnt > 1u && tri_test(r, as_f4(w3), as_f4(w4), as_f4(w5), tNear, h.t, &t, &u, &v)) hit_consider(h, (int32_t)w3.w, t, u, v);
+#if PT_LEAF_MAX > 2
+                for (uint32_t k = 2; k < cnt; ++k)
+                {
+                    const uint4* tp = tris + (size_t)(first + k) * 3;
+                    const uint4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
+                    if (tri_test(r, as_f4(p0), as_f4(p1), as_f4(p2), tNear, h.t, &t, &u, &v)) hit_consider(h, (int32_t)p0.w, t, u, v);
+                }
+#endif
+                /* publish: the minimum over everything found for this owner; the lane whose key stands writes u, v */
+                const unsigned long long key = ((unsigned long long)__float_as_uint(h.t) << 32) | (unsigned long long)(uint32_t)h.prim;
+                if (h.prim >= 0) __hip_atomic_fetch_min((unsigned long long*)(ca.best + owner), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_wave_barrier();
+                if (h.prim >= 0 && ca.best[owner] == key) ca.uv[owner] = ((unsigned long long)__float_as_uint(h.v) << 32) | (unsigned long long)__float_as_uint(h.u);
+            }
+            if (next == PT_BVH_EMPTY)
+            {
+                const float lim2 = __uint_as_float((uint32_t)(ca.best[owner] >> 32));
+                float t; int32_t c;
+                while (st.popb(base, &t, &c))
+                {
+                    if (t <= lim2) { next = c; break; }
+                }
+                if (next == PT_BVH_EMPTY) { st.sp = 0; base = 0; }
+            }
+            cur = next;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long k = ca.best[lane];
+    DHit h; h.prim = -1; h.t = tFar; h.u = 0.0f; h.v = 0.0f;
+    if ((uint32_t)k != 0x7fffffffu)
+    {
+        const unsigned long long b = ca.uv[lane];
+        h.prim = (int32_t)(uint32_t)k; h.t = __uint_as_float((uint32_t)(k >> 32)); h.u = __uint_as_float((uint32_t)b); h.v = __uint_as_float((uint32_t)(b >> 32));
     }
     return h;
 }
