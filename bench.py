@@ -133,20 +133,34 @@ class Run:
             a[k] = a.get(k, 0) + getattr(s, k)
 
     def work_per_ray(self, i):
-        """per-ray node / triangle counts of the batched traversal launches, MEASURED by the counting build of the kernel on
-        one more frame of the same workload (outside the timed region)"""
+        """per-ray node / triangle counts, MEASURED by the counting build of the traversal kernel on two more frames of the same
+        workload (outside the timed region): one under the library's own tail policy -- what the batched launches of the timed
+        steps traced -- and one with every bounce as a wavefront, i.e. ALL rays of a sample; the difference is what the tail
+        kernel traced (the same rays, whoever walks them)"""
         api.work_counters(True)
         self.step(i)
-        nodes, tris, crays, worst = api.work_counters(False)
-        crays = max(crays, 1)
-        return nodes / crays, tris / crays, worst
+        nb, tb, rb, worst = api.work_counters(False)
+        pinned = os.environ.get("PIMGPU_TAIL_BOUNCE")
+        os.environ["PIMGPU_TAIL_BOUNCE"] = "-1"
+        try:
+            api.work_counters(True)
+            self.step(i)
+            na, ta, ra, worst_all = api.work_counters(False)
+        finally:
+            if pinned is None: os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
+            else: os.environ["PIMGPU_TAIL_BOUNCE"] = pinned
+        batched = (nb / max(rb, 1), tb / max(rb, 1), worst)
+        rt = max(ra - rb, 1)
+        tail = (max(na - nb, 0) / rt, max(ta - tb, 0) / rt, worst_all)
+        return batched, tail
 
     def rooflines(self, steps, dt_ms_per_step):
         """one entry per kernel class with its share of the step.  `achieved` = ALGORITHMIC bytes / device time of the kernel's
         launches (events attached to the dispatches, on the library's stream)."""
         a = self.acc
-        nodes, tris, worst = self.work_per_ray(steps)
+        (nodes, tris, worst), (tnodes, ttris, tworst) = self.work_per_ray(steps)
         b_ray = 48.0 + 64.0 * nodes + 48.0 * tris
+        b_ray_tail = 48.0 + 64.0 * tnodes + 48.0 * ttris
         rays = a["extensionRays"] + a["shadowRays"] + a["otherRays"]
         batched = rays - a["tailRays"]
         launches = max(a["traceLaunches"], 1)
@@ -184,10 +198,12 @@ class Run:
         wpb = a["wavefrontPathBounces"]
         out.append(entry("k_shade_a<FAST+SLOW>", a["shadeAMs"], wpb * B_SHADE_A, wpb, "path-bounce", B_SHADE_A))
         out.append(entry("k_shade_b<FAST+SLOW>", a["shadeBMs"], wpb * B_SHADE_B, wpb, "path-bounce", B_SHADE_B))
-        tail_bytes = a["tailRays"] * b_ray + a["tailPathBounces"] * (B_SHADE_A + B_SHADE_B)
+        tail_bytes = a["tailRays"] * b_ray_tail + a["tailPathBounces"] * (B_SHADE_A + B_SHADE_B)
         out.append(entry("k_tail", a["tailMs"], tail_bytes, a["tailRays"], "ray (+ its share of the bounce's shading)",
                          tail_bytes / max(a["tailRays"], 1), paths_per_step=a["tailPaths"] / steps,
-                         note="latency-bound: one lane per path runs the remaining bounces serially (DESIGN.md section 4); bytes use k_trace's per-ray figure"))
+                         nodes_per_ray=tnodes, tris_per_ray=ttris,
+                         note="one lane per path, the two rays of a bounce walked by the whole wave (DESIGN.md section 4); nodes / triangles per ray: "
+                              "the counting build's figures for all rays of a sample minus those of the batched launches"))
         return out
 
     def close(self):

@@ -976,14 +976,13 @@ int stddev_scratch_setup(int device)
 /* host: the bounce loop                                                                           */
 
 /*
- * Where the wavefront hands over to the tail kernel.  The queue lengths are device-side; the host uses those of the
- * PREVIOUS call (progressive rendering repeats the same camera and scene), read back with the statistics: the first
- * bounce whose queue was shorter than 1/kTailFraction of the batch.  The choice only moves time around (k_tail's
- * header), so a stale history is harmless; PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
+ * Where the wavefront hands over to the tail kernel.  A batch that is small enough goes to the tail kernel whole (bounce
+ * 0: the integrator as ONE launch); a larger one runs wavefront bounces until its queue is that short.  The queue lengths
+ * are device-side; the host uses those of the PREVIOUS call (progressive rendering repeats the same camera and scene),
+ * read back with the statistics.  The choice only moves time around (k_tail's header), so a stale history is harmless;
+ * PIMGPU_TAIL_BOUNCE forces it (tests sweep it), negative = never.
  */
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
-static const int kTailFraction = std::max(1, env_int("PIMGPU_TAIL_FRACTION", 2));      /* tuning knobs, not API */
-static const int kTailMaxPaths = std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 1500000));
 static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /* 0: 12 or 16 with the build below */
 /* Two builds of k_tail: 168 VGPRs (3 waves per SIMD, 76 B of spills) and <= 128 VGPRs with more spills (4 per SIMD).  A
  * tree that lives in L2 leaves little latency to hide and the spills cost more than the extra waves give; a tree served
@@ -994,13 +993,14 @@ static constexpr int64_t kTailDenseTreeBytes = 8ll << 20;
 static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
     if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
+    /* Per path-bounce the tail kernel costs more than the batched launches at scale and less below a few million paths,
+     * where the wavefront's launches sit near their latency floors and its queues cross HBM between them.  Swept with the
+     * cooperative walk (traverse_coop) in place, switch at bounce 0 / 1 / 2: 1 M triangles 1080p (2.07 M paths) 4.66 / 4.95 /
+     * 5.67 ms, Cornell 1080p 1.77 / 1.97 / 2.18, 1 M triangles 4K (8.3 M paths, 2.8 M at bounce 1) 15.9 / 13.85 / 13.87.
+     * Knobs, not API: the threshold in paths and a divisor of the batch size (off = 1). */
+    const int64_t threshold = std::min<int64_t>((int64_t)n / std::max(1, env_int("PIMGPU_TAIL_FRACTION", 1)), std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 2500000)));
+    if ((int64_t)n <= threshold) return 0;
     if (g.historyN != n || g.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
-    /* ... and in absolute terms no more than about 1.5 M paths, a few times what the machine holds at k_tail's occupancy
-     * (its lanes take further paths as theirs end): per path-bounce the tail costs about 1.4 x the batched launches, which
-     * pays as long as the wavefront's launches sit near their latency floors.  Swept after the inline traversal went to
-     * one round trip per step (1 M triangles: switch at bounce 1 / 2 / 3 -> 5.96 / 6.43 / 6.9 ms at 1080p, 16.1 / 14.9 /
-     * 15.2 ms at 4K; Cornell 1080p 2.10 / 2.19) */
-    const int64_t threshold = std::min<int64_t>((int64_t)n / kTailFraction, kTailMaxPaths);
     for (int32_t b = 1; b < g.historyBounces && b < bounceLimit; ++b)
         if ((int64_t)g.history[b] < threshold) return b;
     return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;

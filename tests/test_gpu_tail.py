@@ -14,7 +14,7 @@ from tests.test_gpu_image import _render_both
 pytestmark = pytest.mark.gpu
 
 
-KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_DENSE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS", "PIMGPU_NEE_TARGET")
+KNOBS = ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_DENSE", "PIMGPU_GROUPS", "PIMGPU_GROUP_STAGGER", "PIMGPU_GROUP_MIN_PATHS", "PIMGPU_NEE_TARGET", "PIMGPU_TAIL_MAX_PATHS")
 
 
 @pytest.fixture
@@ -47,33 +47,44 @@ def test_tail_refractive_sky_media_and_roulette_bit_exact(tail_env, switch):
 
 
 def test_tail_policy_uses_the_previous_call(tail_env):
-    """without the override the host switches where the previous call's queue fell below 1/6 of the batch: the first
-    call runs every bounce as a wavefront, later calls hand the deep bounces to the tail kernel -- same bits either way"""
+    """a batch below the threshold (PIMGPU_TAIL_MAX_PATHS) goes to the tail kernel whole, from the first call on; above it
+    the host switches where the previous call's queue fell below the threshold: the first call runs every bounce as a
+    wavefront, later calls hand the deep bounces to the tail kernel -- same bits every way"""
     os.environ.pop("PIMGPU_TAIL_BOUNCE", None)
     gpu_init()
     sc = scenes.cornell_box()
-    g = api.Scene(sc.desc)
     W, H = 160, 90
-    t = api.Trace(W, H)
-    dof = scenes.default_dof()
-    seen = []
-    for s in range(3):
-        t.trace(g, scenes.pt_test_camera(), dof, scenes.trace_params(s, seed=3, max_bounces=12))
-        st = t.stats()
-        seen.append((st.bounces, st.tailRays))
-    assert seen[0] == (12, 0)                          # no history: all wavefront
-    assert 1 <= seen[1][0] < 12 and seen[1][1] > 0     # history: short queues go to the tail kernel
-    assert seen[2][0] == seen[1][0]
-    a = t.download()[0]
+    images = []
+    for max_paths in (None, str(W * H // 3)):
+        if max_paths is None: os.environ.pop("PIMGPU_TAIL_MAX_PATHS", None)
+        else: os.environ["PIMGPU_TAIL_MAX_PATHS"] = max_paths
+        g = api.Scene(sc.desc)                          # a fresh scene: the light histograms adapt from frame to frame
+        t = api.Trace(W, H)
+        dof = scenes.default_dof()
+        seen = []
+        for s in range(3):
+            t.trace(g, scenes.pt_test_camera(), dof, scenes.trace_params(s, seed=3, max_bounces=12))
+            st = t.stats()
+            seen.append((st.bounces, st.tailRays))
+        if max_paths is None:
+            assert all(b == 0 and r > 0 for b, r in seen)      # the whole integrator as one launch
+        else:
+            assert seen[0] == (12, 0)                          # no history: all wavefront
+            assert 1 <= seen[1][0] < 12 and seen[1][1] > 0     # history: short queues go to the tail kernel
+            assert seen[2][0] == seen[1][0]
+        images.append(t.download()[0])
+        t.close(); g.close()
     os.environ["PIMGPU_TAIL_BOUNCE"] = "-1"
-    g2 = api.Scene(sc.desc)                             # a fresh scene: the light histograms adapt from frame to frame
+    g2 = api.Scene(sc.desc)
     t2 = api.Trace(W, H)
     dof2 = scenes.default_dof()
     for s in range(3):
         t2.trace(g2, scenes.pt_test_camera(), dof2, scenes.trace_params(s, seed=3, max_bounces=12))
         assert t2.stats().tailRays == 0
-    assert (t2.download()[0].view(np.uint32) == a.view(np.uint32)).all()
-    t.close(); t2.close(); g.close(); g2.close()
+    ref = t2.download()[0]
+    for a in images:
+        assert (ref.view(np.uint32) == a.view(np.uint32)).all()
+    t2.close(); g2.close()
 
 
 def test_lightmap_bake_through_the_tail_bit_exact(tail_env):
