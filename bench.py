@@ -175,25 +175,29 @@ class Run:
             e.update(extra)
             return e
 
-        tr = load_traffic(self.name)
-        traffic = tr.get("bytes_per_launch") if tr else None
+        trw = load_traffic(self.name) or {}
+        per_kernel = trw.get("kernels") or ({trw["kernel"]: trw} if trw.get("kernel") else {})
+
+        def attach_traffic(e, label, launch_ms):
+            """HBM-side bytes per launch of this kernel class from the committed PMC passes (not this run), and the DRAM-side rate they give"""
+            tr = per_kernel.get(label)
+            e["traffic"] = tr.get("bytes_per_launch") if tr else None
+            if tr and launch_ms > 0:
+                e["hbm_measured"] = {"bytes_per_launch": tr["bytes_per_launch"], "GBps": tr["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9,
+                                     "frac_of_peak": tr["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "l2_hit_rate": tr.get("l2_hit_rate"),
+                                     "source": f"profiles/traffic.json [{tr.get('tag')}]: rocprofv3 --pmc passes of `{tr.get('command')}`, NOT measured in this run"}
+                e["traffic_source"] = "profiles/traffic.json (committed PMC measurement of this workload, not this run)"
+
         avg_launch_ms = a["traceMs"] / launches
         t = entry("k_trace<closest>", a["traceMs"], batched * b_ray, batched, "ray", b_ray,
                   nodes_per_ray=nodes, tris_per_ray=tris, max_nodes_one_ray=worst, rays_per_launch=batched / launches,
-                  launches_per_step=launches / steps, avg_launch_ms=avg_launch_ms, bytes_per_launch=batched / launches * b_ray,
-                  traffic=traffic)
+                  launches_per_step=launches / steps, avg_launch_ms=avg_launch_ms, bytes_per_launch=batched / launches * b_ray)
         # the honest ceiling: the algorithmic bytes are mostly cache hits (the tree lives in L2 / the Infinity Cache), so the
         # HBM-side rate is the measured one, and what binds the kernel is the vector L1's lookup rate and VALU issue
         t["algorithmic_note"] = ("achieved/frac count 64 B per node visit and 48 B per triangle test as if each came from HBM (SURVEY 8d's "
                                  "contract); most are L2 / Infinity Cache hits -- see hbm_measured for the DRAM-side rate")
-        if tr:
-            t["hbm_measured"] = {"bytes_per_launch": traffic, "GBps": traffic / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else None,
-                                 "frac_of_peak": traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_launch_ms > 0 else None,
-                                 "l2_hit_rate": tr.get("l2_hit_rate"),
-                                 "source": f"profiles/traffic.json [{tr.get('tag')}]: rocprofv3 --pmc passes of `{tr.get('command')}`, NOT measured in this run"}
-            t["traffic_source"] = "profiles/traffic.json (committed PMC measurement of this workload, not this run)"
-        t["binding_resource"] = tr.get("binding_resource") if tr and tr.get("binding_resource") else \
-            "vector-L1 (TCP) lookups and VALU issue at partial lane utilisation, not HBM bytes (profiles/*_pmc_summary.txt)"
+        attach_traffic(t, "k_trace<closest>", avg_launch_ms if a["traceMs"] > 0 and batched > launches else 0.0)
+        t["binding_resource"] = "vector-L1 (TCP) lookups and VALU issue at partial lane utilisation, not HBM bytes (profiles/*_pmc_summary.txt)"
         out.append(t)
         wpb = a["wavefrontPathBounces"]
         out.append(entry("k_shade_a<FAST+SLOW>", a["shadeAMs"], wpb * B_SHADE_A, wpb, "path-bounce", B_SHADE_A))
@@ -202,8 +206,10 @@ class Run:
         out.append(entry("k_tail", a["tailMs"], tail_bytes, a["tailRays"], "ray (+ its share of the bounce's shading)",
                          tail_bytes / max(a["tailRays"], 1), paths_per_step=a["tailPaths"] / steps,
                          nodes_per_ray=tnodes, tris_per_ray=ttris,
+                         binding_resource="VALU issue (about 80 % busy) at about 29 of 64 lanes per instruction (profiles/*_pmc_summary.txt)",
                          note="one lane per path, the two rays of a bounce walked by the whole wave (DESIGN.md section 4); nodes / triangles per ray: "
                               "the counting build's figures for all rays of a sample minus those of the batched launches"))
+        attach_traffic(out[-1], "k_tail", a["tailMs"] / steps)
         return out
 
     def close(self):
