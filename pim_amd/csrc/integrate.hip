@@ -47,6 +47,8 @@ static constexpr int kShadeThreads = 512;
 
 /* counters[]: [0],[1] queue lengths, [2],[3] slow-list lengths, [PT_COUNTS_BASE + b] queue length at the start of bounce b
  * (read back with the statistics: the host's tail policy of the next call) */
+#define PT_PARKED      5     /* counters[]: paths parked for the tail kernel */
+#define PT_PARK_COUNTED 0x40000000   /* in a parked ray's bounce word: its extension ray is already in the statistics */
 #define PT_COUNTS_BASE 8
 #define PT_COUNTS_MAX  56
 
@@ -56,7 +58,7 @@ void WorkBuffers::release()
     hipFree(ps.rng); hipFree(ps.ro); hipFree(ps.rd); hipFree(ps.atten); hipFree(ps.lum); hipFree(ps.albedo); hipFree(ps.normal);
     hipFree(ps.nee0); hipFree(ps.nee1);
     for (int i = 0; i < 2; ++i) { hipFree(extO[i]); hipFree(extD[i]); hipFree(queue[i]); }
-    hipFree(neeO); hipFree(neeD); hipFree(extHit); hipFree(neeHit); hipFree(neeTarget); hipFree(counters); hipFree(stats); hipFree(results); hipFree(slowA); hipFree(slowB);
+    hipFree(neeO); hipFree(neeD); hipFree(extHit); hipFree(neeHit); hipFree(neeTarget); hipFree(parkSlot); hipFree(parkO); hipFree(parkD); hipFree(counters); hipFree(stats); hipFree(results); hipFree(slowA); hipFree(slowB);
     *this = WorkBuffers();
 }
 
@@ -89,7 +91,7 @@ int WorkBuffers::ensure_paths(int64_t n)
     A(&ps.lum, sizeof(float4)); A(&ps.albedo, sizeof(float4)); A(&ps.normal, sizeof(float4));
     A(&ps.nee0, sizeof(float4)); A(&ps.nee1, sizeof(float4));
     for (int i = 0; i < 2; ++i) { A(&extO[i], sizeof(float4)); A(&extD[i], sizeof(float4)); A(&queue[i], sizeof(int32_t)); }
-    A(&slowA, sizeof(int32_t)); A(&slowB, sizeof(int32_t)); A(&neeO, sizeof(float4)); A(&neeD, sizeof(float4)); A(&extHit, sizeof(DHit)); A(&neeHit, sizeof(DHit)); A(&neeTarget, sizeof(int32_t)); A(&results, sizeof(PimResult));
+    A(&slowA, sizeof(int32_t)); A(&slowB, sizeof(int32_t)); A(&neeO, sizeof(float4)); A(&neeD, sizeof(float4)); A(&extHit, sizeof(DHit)); A(&neeHit, sizeof(DHit)); A(&neeTarget, sizeof(int32_t)); A(&parkSlot, sizeof(int32_t)); A(&parkO, sizeof(float4)); A(&parkD, sizeof(float4)); A(&results, sizeof(PimResult));
     if (!ok) { set_error("out of device memory for %lld paths", (long long)n); return PIMGPU_E_NOMEM; }
     pathCap = n;
     return PIMGPU_OK;
@@ -133,6 +135,10 @@ struct StageArgs
     int32_t tailLanes;              /* k_tail: lanes of each wave that take paths */
     unsigned long long* spill;      /* k_tail: overflow area of the traversal stacks (TraceResources::spill) */
     int32_t stackCap;               /* entries a traversal stack may hold (trace_stack_cap) */
+    /* paths the FAST shade_a cannot finish (a medium collision) are PARKED: taken out of the wavefront with their extension ray and
+     * bounce, and run from there by the tail kernel at the end of the call (counters[PT_PARKED]); null: listed for shade_a<SLOW> */
+    int32_t* parkSlot; float4* parkO; float4* parkD;
+    int32_t tailMainEmpty;          /* k_tail: only the parked paths (the wavefront finished the others) */
 };
 
 __device__ __forceinline__ v4 ld4(const float4* p, int64_t i) { const float4 v = p[i]; return f4_v(v.x, v.y, v.z, v.w); }
@@ -572,8 +578,27 @@ __global__ __launch_bounds__(kShadeThreads, SLOW ? 1 : PT_SHADE_WAVES) void k_sh
         }
         if (!SLOW)
         {
-            const int32_t q = wave_append(&a.counters[2], deferred);
-            if (deferred) a.slowA[q] = pos;
+            if (a.parkSlot)
+            {
+                /* out of the wavefront: no direct-light ray, nothing for shade_b to do, and the tail kernel starts the path again
+                 * from this bounce's extension ray (the stage has written nothing) */
+                const int32_t q = wave_append(&a.counters[PT_PARKED], deferred);
+                if (deferred)
+                {
+                    const float4 eo = a.extO[pos];
+                    a.parkSlot[q] = a.queueIn[pos];
+                    a.parkO[q] = make_float4(eo.x, eo.y, eo.z, __int_as_float(a.bounce | PT_PARK_COUNTED));
+                    a.parkD[q] = a.extD[pos];
+                    a.ps.nee0[a.queueIn[pos]] = make_float4(__int_as_float(PT_NEE_DEAD), 0.0f, 0.0f, 0.0f);
+                    a.neeD[pos] = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
+                    if (a.neeTarget) a.neeTarget[pos] = -1;
+                }
+            }
+            else
+            {
+                const int32_t q = wave_append(&a.counters[2], deferred);
+                if (deferred) a.slowA[q] = pos;
+            }
         }
     }
     __shared__ int32_t sh[2 + kShadeThreads / 64];
@@ -786,9 +811,10 @@ static constexpr int kTailThreads = 64;       /* one wave per block: the schedul
 template <int OCC>
 __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs a)
 {
-    const int32_t count = a.counters[a.inSel];
+    const int32_t countPark = a.parkSlot ? a.counters[PT_PARKED] : 0;
+    const int32_t count = countPark + (a.tailMainEmpty ? 0 : a.counters[a.inSel]);       /* the parked paths first (they have the most bounces left), then the queue */
     uint32_t ext = 0, shadow = 0, other = 0; bool overflow = false;
-    bool have = false;
+    bool have = false, counted = false;
     int32_t slot = 0, b = 0;
     float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = o;
     /* the traversal stack of the two rays of a bounce: LDS (lane-interleaved) + spill area, as in k_trace -- a pop from
@@ -812,7 +838,12 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
         if (want)
         {
             if (pos >= count) drained = true;
-            else { slot = a.queueIn[pos]; o = a.extO[pos]; d = a.extD[pos]; b = a.bounce; have = true; }
+            else if (pos >= countPark) { const int32_t k = pos - countPark; slot = a.queueIn[k]; o = a.extO[k]; d = a.extD[k]; b = a.bounce; have = true; }
+            else
+            {
+                slot = a.parkSlot[pos]; o = a.parkO[pos]; d = a.parkD[pos];
+                b = __float_as_int(o.w) & ~PT_PARK_COUNTED; counted = true; o.w = 0.0f; have = true;
+            }
         }
         if (__ballot(have) == 0ull) break;
 #ifdef PT_TAIL_PROF
@@ -826,7 +857,8 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
         StageAOut ra; ra.nO = make_float4(0.0f, 0.0f, 0.0f, 0.0f); ra.nD = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
         if (have)
         {
-            ++ext;
+            if (!counted) ++ext;                /* a parked path's ray was counted by the shade_a launch that parked it */
+            counted = false;
             ra = stage_a<true, false>(s, a, slot, eh, b, st);
             shadow += ra.shadow; other += ra.other; overflow |= ra.overflow;
         }
@@ -1083,6 +1115,33 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
      * +4% of k_shade_a on either scene) */
     const int forceTarget = env_int("PIMGPU_NEE_TARGET", -1);                   /* -1: by tree size; 0 / 1 force (tests) */
     const bool targeted = forceTarget >= 0 ? forceTarget != 0 : 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount > (8ll << 20);
+    /* paths whose shade_a stage meets the rare heavy case (a medium collision) leave the wavefront and are finished by the tail
+     * kernel at the end of the call, instead of a shade_a<SLOW> launch per bounce that costs its latency floor for a fraction of a
+     * per cent of the paths (1 M triangles 4K: 0.19 ms per bounce).  Off when the caller forbids the tail kernel (tests of the SLOW
+     * launches). */
+    const bool park = tailBounce > 0 && !(getenv("PIMGPU_TAIL_BOUNCE") && atoi(getenv("PIMGPU_TAIL_BOUNCE")) < 0) && env_int("PIMGPU_PARK", 1) != 0;
+    bool tailLaunched = false;
+    auto launch_tail = [&](StageArgs& a, int32_t b, bool mainEmpty)
+    {
+        /* One lane per path of the expected queue (the previous call's length at this bounce), but no more waves than
+         * the machine holds at k_tail's occupancy: lanes take further paths as theirs end */
+        const int64_t expect = mainEmpty ? std::max<int64_t>(4096, n / 64) : ((g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n);
+        a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
+        a.tailMainEmpty = mainEmpty ? 1 : 0;
+        const int64_t treeBytes = 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount;
+        const int forceDense = env_int("PIMGPU_TAIL_DENSE", -1);            /* -1: by tree size; 0 / 1 force (tests) */
+        const bool dense = forceDense >= 0 ? forceDense != 0 : treeBytes > kTailDenseTreeBytes;
+        const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 12);
+        const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * wavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
+        const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
+        timed(3);
+        if (dense) PT_LAUNCH(k_tail<4>, tailBlocks, kTailThreads, scene->d, a);
+        else PT_LAUNCH(k_tail<3>, tailBlocks, kTailThreads, scene->d, a);
+        if (!mainEmpty) g.tailBounce = b;
+        tailLaunched = true;
+        if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
+    };
+    StageArgs last = {};
     for (int32_t b = 0; b < bounceLimit; ++b)
     {
         const int in = b & 1, out = in ^ 1;
@@ -1090,33 +1149,20 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         a.ps = w.ps; a.queueIn = w.queue[in] + first; a.queueOut = w.queue[out] + first; a.counters = g.counters; a.inSel = in;
         a.extO = w.extO[in] + first; a.extD = w.extD[in] + first; a.extHit = w.extHit + first; a.neeHit = w.neeHit + first;
         a.neeO = w.neeO + first; a.neeD = w.neeD + first; a.neeHitOut = w.neeHit + first; a.neeTarget = targeted ? w.neeTarget + first : nullptr;
+        a.parkSlot = park ? w.parkSlot + first : nullptr; a.parkO = w.parkO + first; a.parkD = w.parkD + first; a.tailMainEmpty = 0;
         a.extOOut = w.extO[out] + first; a.extDOut = w.extD[out] + first; a.results = w.results; a.stats = g.stats;
         a.bounce = b; a.bounceLimit = bounceLimit; a.slowA = w.slowA + first; a.slowB = w.slowB + first; a.tailLanes = 64; a.spill = g.trace->spill; a.stackCap = trace_stack_cap();
         if (b >= tailBounce)
         {
-            /* the queue is short by now (or the caller forced it): one launch finishes every path.
-             * One lane per path of the expected queue (the previous call's length at this bounce), but no more waves than
-             * the machine holds at k_tail's occupancy (2 per SIMD): lanes take further paths as theirs end */
-            const int64_t expect = (g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n;
-            a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
-            const int64_t treeBytes = 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount;
-            const int forceDense = env_int("PIMGPU_TAIL_DENSE", -1);            /* -1: by tree size; 0 / 1 force (tests) */
-            const bool dense = forceDense >= 0 ? forceDense != 0 : treeBytes > kTailDenseTreeBytes;
-            const int wavesPerCu = kTailWavesPerCu > 0 ? kTailWavesPerCu : (dense ? 16 : 12);
-            const int64_t want = std::min<int64_t>((int64_t)g_lib.cuCount * wavesPerCu, (expect + a.tailLanes - 1) / a.tailLanes);
-            const int tailBlocks = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)g.trace->gridBlocks * (256 / kTailThreads)));
-            timed(3);
-            if (dense) PT_LAUNCH(k_tail<4>, tailBlocks, kTailThreads, scene->d, a);
-            else PT_LAUNCH(k_tail<3>, tailBlocks, kTailThreads, scene->d, a);
-            g.tailBounce = b;
-            if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; }
+            /* the queue is short by now (or the caller forced it): one launch finishes every path */
+            launch_tail(a, b, false);
             break;
         }
         ++g.wavefrontBounces;
         timed(0);
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.extO, a.extD, w.extHit + first, n, g.counters + in, st, t0, t1))) break;
         timed(1); PT_LAUNCH(k_shade_a<false>, blocks, kShadeThreads, scene->d, a);
-        timed(1); PT_LAUNCH(k_shade_a<true>, slowBlocks, kShadeThreads, scene->d, a);
+        if (!park) { timed(1); PT_LAUNCH(k_shade_a<true>, slowBlocks, kShadeThreads, scene->d, a); }
         half_done();
         timed(0);
         if ((rc = trace_closest(scene->d.bvh, g.trace, a.neeO, a.neeD, w.neeHit + first, n, g.counters + in, st, t0, t1, a.neeTarget))) break;
@@ -1124,7 +1170,10 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
         timed(2); PT_LAUNCH(k_shade_b<true>, slowBlocks, kShadeThreads, scene->d, a);
         half_done();
         if (hipGetLastError() != hipSuccess) { set_error("integrator launch failed"); rc = PIMGPU_E_DEVICE; break; }
+        last = a;
     }
+    /* the wavefront ran to the bounce limit: the parked paths still have to be finished */
+    if (rc == PIMGPU_OK && park && !tailLaunched && g.wavefrontBounces > 0) launch_tail(last, last.bounce, true);
     if (!staggered) hipEventRecord(g.stagger, st);
 #undef PT_LAUNCH
     return rc;

@@ -71,6 +71,7 @@ struct WorkBuffers
     float4* extO[2] = { nullptr, nullptr }; float4* extD[2] = { nullptr, nullptr };   /* extension rays, by queue position */
     float4* neeO = nullptr; float4* neeD = nullptr;
     DHit* extHit = nullptr; DHit* neeHit = nullptr;
+    int32_t* parkSlot = nullptr; float4* parkO = nullptr; float4* parkD = nullptr;   /* paths parked for the tail kernel (integrate.hip) */
     int32_t* neeTarget = nullptr;       /* per NEE ray: the light triangle it is aimed at (light-sampling branch), -1 = a plain closest-hit query */
     int32_t* queue[2] = { nullptr, nullptr };
     int32_t* slowA = nullptr; int32_t* slowB = nullptr;     /* queue positions deferred to the SLOW builds of the stages */

@@ -69,7 +69,7 @@ def test_tail_policy_uses_the_previous_call(tail_env):
         if max_paths is None:
             assert all(b == 0 and r > 0 for b, r in seen)      # the whole integrator as one launch
         else:
-            assert seen[0] == (12, 0)                          # no history: all wavefront
+            assert seen[0][0] == 12 and seen[0][1] < 200        # no history: all wavefront (but for the few parked paths)
             assert 1 <= seen[1][0] < 12 and seen[1][1] > 0     # history: short queues go to the tail kernel
             assert seen[2][0] == seen[1][0]
         images.append(t.download()[0])
