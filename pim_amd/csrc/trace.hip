@@ -42,7 +42,7 @@ static constexpr int kTraceBlocksPerCU = 8;
 #define PT_POP_MAX 1
 #endif
 #ifndef PT_TRI_VOTE
-#define PT_TRI_VOTE 16
+#define PT_TRI_VOTE 10
 #endif
 
 #ifndef PT_TRACE_WAVES
