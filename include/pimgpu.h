@@ -342,6 +342,12 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* trace, const PimCamera* camera
 /* copy the running-mean buffers to host float3[W*H] arrays (any may be NULL);
  * the reference's callers read PtTrace.color/albedo/normal on the host (render_system.c:306-352) */
 int pimgpu_trace_download(const PimTrace* trace, float* color, float* albedo, float* normal);
+/* Pt_Trace as the reference's callers use it (path_tracer.h:94, render_system.c:306-352: the host images are read right
+ * after the call): pimgpu_trace_image and pimgpu_trace_download in one call (any image pointer may be NULL).  The pixels are
+ * traced in shares, one after the other, and a share's part of the images travels to the host while the next share is
+ * traced; the result is the same bit for bit.  Page-locked images (pimgpu_host_alloc) copy at the link's rate. */
+int pimgpu_trace_image_host(PimScene* scene, PimTrace* trace, const PimCamera* camera, PimDofInfo* dof, const PimTraceParams* params,
+    float* color, float* albedo, float* normal);
 /* device addresses of the float3 buffers (for torch.distributed reduce without a host copy) */
 int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDev, void** normalDev);
 /* the same buffers copied device-to-device into caller-owned HBM (any pointer may be NULL): what a multi-GPU

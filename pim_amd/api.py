@@ -114,7 +114,7 @@ EXPORTS = [
     "pimgpu_scene_info", "pimgpu_scene_download_lights",
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
-    "pimgpu_trace_download", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
+    "pimgpu_trace_download", "pimgpu_trace_image_host", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc", "pimgpu_init_devices", "pimgpu_device_count",
@@ -320,6 +320,12 @@ class Trace:
 
     def trace(self, scene, camera, dof, params):
         check(self.lib.pimgpu_trace_image(scene.handle, self.handle, C.byref(camera), C.byref(dof), C.byref(params)), "pimgpu_trace_image")
+
+    def trace_to_host(self, scene, camera, dof, params, color, albedo=None, normal=None):
+        """pimgpu_trace_image_host: the sample and the copy of the images to the host arrays (float32 [W*H, 3]) in one call"""
+        check(self.lib.pimgpu_trace_image_host(scene.handle, self.handle, C.byref(camera), C.byref(dof), C.byref(params),
+                                               _ptr(color), _ptr(albedo) if albedo is not None else None, _ptr(normal) if normal is not None else None),
+              "pimgpu_trace_image_host")
 
     def download(self):
         n = self.width * self.height

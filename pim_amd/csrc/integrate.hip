@@ -253,6 +253,7 @@ struct CameraArgs
     uint32_t sampleIndex, seed;
     const float* focalDev;          /* non-null: dof.focalLength of this frame, left on the device by k_focus_update */
     int32_t pixelBegin, pixelCount; /* the band of pixels this launch renders (multi-device: rows of the image) */
+    int32_t slotBegin;              /* path slot of the band's first pixel (shares of an image: pimgpu_trace_image_host) */
 };
 
 /* CalculateDof, pt.c:2418-2452 */
@@ -286,9 +287,10 @@ __global__ void k_focus_update(const DHit* __restrict__ hit, float focalLength, 
 /* TraceFn up to Pt_TraceRay, pt.c:2514-2545 */
 __global__ __launch_bounds__(256) void k_init_image(PathState ps, float4* extO, float4* extD, int32_t* queue, CameraArgs c)
 {
-    const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;       /* path slot; pixel = pixelBegin + slot (a band of the image) */
-    if (slot >= c.pixelCount) return;
-    const int32_t i = c.pixelBegin + slot;
+    const int32_t local = blockIdx.x * blockDim.x + threadIdx.x;      /* pixel = pixelBegin + local (a band of the image), path slot = slotBegin + local */
+    if (local >= c.pixelCount) return;
+    const int32_t slot = c.slotBegin + local;
+    const int32_t i = c.pixelBegin + local;
     const int32_t cx = i % c.width, cy = i / c.width;
     const float rcpX = 1.0f / (float)c.width, rcpY = 1.0f / (float)c.height;
     Ctx ctx = ctx_make();
@@ -1367,7 +1369,12 @@ int pimgpu_trace_clear(PimTrace* t)
 }
 
 /* one context renders the pixels [pixelBegin, pixelBegin + n) of the image into its copy of the PtTrace buffers */
-static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p, int32_t pixelBegin, int32_t n)
+/* hostColor / hostAlbedo / hostNormal (any may be null; all null: nothing is copied): the caller's float3[W*H] host images.  With
+ * them the band is rendered in SHARES of pixels, one after the other, each on its own stream, and a share's part of the images
+ * is copied to the host behind its resolve -- while the next share is being traced.  A path depends on nothing but its own
+ * Prng stream and the scene, so the shares do not change a bit of the image (the groups of integrate_image, run in sequence). */
+static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p, int32_t pixelBegin, int32_t n,
+    float* hostColor = nullptr, float* hostAlbedo = nullptr, float* hostNormal = nullptr)
 {
     int rc = check_ready(); if (rc) return rc;
     memset(&t->stats, 0, sizeof(t->stats));
@@ -1405,13 +1412,76 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
         c.slope = f2_v(aspect * tn, tn);
     }
     c.dof = *dof; c.width = t->width; c.height = t->height; c.sampleIndex = p->sampleIndex; c.seed = p->seed; c.focalDev = focalDev;
-    c.pixelBegin = pixelBegin; c.pixelCount = n;
-    if (n > 0) k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
+    c.pixelBegin = pixelBegin; c.pixelCount = n; c.slotBegin = 0;
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
+    const bool toHost = hostColor || hostAlbedo || hostNormal;
+    /* shares of at least 256 k pixels, 2 by default (PIMGPU_HOST_SHARES; measured at 1080p, 1 / 2 / 4 / 8 shares: 3.17 / 2.80 / 3.27 /
+     * 4.29 ms per call -- every share's launch ends with its own slowest waves) */
+    int shares = toHost ? std::max(1, std::min(kMaxGroups, env_int("PIMGPU_HOST_SHARES", 2))) : 1;
+    shares = (int)std::min<int64_t>(shares, std::max<int64_t>(1, n / std::max(64, env_int("PIMGPU_HOST_SHARE_MIN", 1 << 18))));
+    if (g_lib.trace.counting) shares = 1;            /* the work counters live in the main stream's resources */
+    if (shares > 1)
+    {
+        const bool timeTrace = p->updateDists >= 0 && !getenv("PIMGPU_NO_EVENTS");
+        for (int k = 0; k < shares; ++k) if ((rc = g_lib.ensure_group(k))) return rc;
+        /* the first share is the larger one (PIMGPU_HOST_FIRST eighths of its equal part, default 10 = 5/4): the copy that is left
+         * over at the end is the LAST share's */
+        const int32_t firstEighths = std::max(1, std::min(8 * shares - 1, env_int("PIMGPU_HOST_FIRST", 10)));
+        const int32_t firstCount = (int32_t)(((int64_t)n * firstEighths / (8 * shares) + 63) & ~(int64_t)63);
+        const int32_t per = shares > 1 ? (int32_t)((((int64_t)(n - firstCount) + shares - 2) / (shares - 1) + 63) & ~(int64_t)63) : n;
+        int used = 0;
+        for (int k = 0; k < shares && rc == PIMGPU_OK; ++k)
+        {
+            const int32_t first = k == 0 ? 0 : (int32_t)std::min<int64_t>(n, firstCount + (int64_t)per * (k - 1));
+            const int32_t count = std::min<int32_t>(k == 0 ? firstCount : per, n - first);
+            if (count <= 0) break;
+            const bool last = first + count >= n;
+            PathGroup& g = g_lib.groups[k];
+            hipStream_t s = g.stream;                                     /* share 0: the library's stream, with the set-up above */
+            /* a share starts when the one before it has been resolved (unchained, the shares' launches interleave and all end together:
+             * 3.2 instead of 2.8 ms at 1080p) */
+            if (k > 0) PT_HIP(hipStreamWaitEvent(s, g_lib.groups[k - 1].done, 0));
+            c.pixelBegin = pixelBegin + first; c.pixelCount = count; c.slotBegin = first;
+            k_init_image<<<(count + 255) / 256, 256, 0, s>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
+            if ((rc = integrate_enqueue(scene, g, first, count, p->maxBounces, timeTrace, -1))) break;
+            k_resolve_image<<<(count + 255) / 256, 256, 0, s>>>(w.results + first, pixelBegin + first, count, p->sampleWeight, t->color, t->albedo, t->normal);
+            PT_HIP(hipEventRecord(g.done, s));
+            ++used;
+            if (last)
+            {
+                hipEventRecord(e1, s);
+                if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s);
+            }
+            /* this share's pixels go home while the next share is traced */
+            const size_t off = (size_t)(pixelBegin + first) * 3, bytes = sizeof(float) * 3 * (size_t)count;
+            if (hostColor) hipMemcpyAsync(hostColor + off, t->color + off, bytes, hipMemcpyDeviceToHost, s);
+            if (hostAlbedo) hipMemcpyAsync(hostAlbedo + off, t->albedo + off, bytes, hipMemcpyDeviceToHost, s);
+            if (hostNormal) hipMemcpyAsync(hostNormal + off, t->normal + off, bytes, hipMemcpyDeviceToHost, s);
+        }
+        for (int k = used - 1; k >= 0; --k)
+        {
+            float ms = 0.0f;
+            const int r = integrate_finish(g_lib.groups[k], &stats, timeTrace ? &ms : nullptr);      /* waits for the share's stream, copies included */
+            traceMs += ms;
+            if (rc == PIMGPU_OK) rc = r;
+        }
+        if (rc) { for (int k = 0; k < used; ++k) hipStreamSynchronize(g_lib.groups[k].stream); return rc; }
+    }
+    else
+    {
+    if (n > 0) k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr, [&](hipStream_t s)
         { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, pixelBegin, n, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s);
-          if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s); }))) return rc;
+          if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s);
+          if (toHost)
+          {
+              const size_t off = (size_t)pixelBegin * 3, bytes = sizeof(float) * 3 * (size_t)n;
+              if (hostColor) hipMemcpyAsync(hostColor + off, t->color + off, bytes, hipMemcpyDeviceToHost, s);
+              if (hostAlbedo) hipMemcpyAsync(hostAlbedo + off, t->albedo + off, bytes, hipMemcpyDeviceToHost, s);
+              if (hostNormal) hipMemcpyAsync(hostNormal + off, t->normal + off, bytes, hipMemcpyDeviceToHost, s);
+          } }))) return rc;
+    }
     PT_HIP(hipEventSynchronize(e1));
     dof->focalLength = focalHost;                                                  /* DofUpdate updates the caller's struct */
     float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
@@ -1459,6 +1529,24 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     t->stats = sum;
     t->gathered = false;
     return PIMGPU_OK;
+}
+
+int pimgpu_trace_download(const PimTrace* t, float* color, float* albedo, float* normal);
+
+/* Pt_Trace as its callers use it (render_system.c:306-352 read the host images right after the call): the sample and the
+ * copy of the three images to the host in one call, the copy of one share of the pixels running under the tracing of the
+ * next (trace_image_one).  Same images, statistics and autofocus state as pimgpu_trace_image + pimgpu_trace_download. */
+int pimgpu_trace_image_host(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p,
+    float* color, float* albedo, float* normal)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !t || !cam || !dof || !p) { set_error("trace_image_host: NULL argument"); return PIMGPU_E_INVALID; }
+    if (dof->bladeCount <= 0) { set_error("trace_image_host: dof.bladeCount must be positive"); return PIMGPU_E_INVALID; }
+    if (g_libCount <= 1 || !scene->peers[1] || !t->peers[1])
+        return trace_image_one(scene, t, cam, dof, p, 0, t->width * t->height, color, albedo, normal);
+    /* several devices: every device copies its own band (pimgpu_trace_download) */
+    if ((rc = pimgpu_trace_image(scene, t, cam, dof, p))) return rc;
+    return (color || albedo || normal) ? pimgpu_trace_download(t, color, albedo, normal) : PIMGPU_OK;
 }
 
 /* multi-device: bring every band into the copy of context 0 (stddev, device-side readers) */

@@ -330,12 +330,12 @@ void Pt_Trace(PtTrace* trace, PtDofInfo* dof, PtScene* scene, const Camera* came
     p.updateDists = 1;                                   /* ... and UpdateDists (:1034), enqueued with the frame */
     PimDofInfo gdof = dof_to_gpu(dof);
     PimCamera cam; memcpy(&cam, camera, sizeof(cam));
-    if (!ok(pimgpu_trace_image(scene->gpu, ms_traces[slot].gpu, &cam, &gdof, &p), "Pt_Trace")) return;
+    /* the reference's callers read the host images right after Pt_Trace (render_system.c:306-352): the copy of one share of
+     * the pixels runs under the tracing of the next */
+    const bool aovs = ms_config.downloadAovs != 0;
+    if (!ok(pimgpu_trace_image_host(scene->gpu, ms_traces[slot].gpu, &cam, &gdof, &p, &trace->color->x, aovs ? &trace->albedo->x : NULL, aovs ? &trace->normal->x : NULL), "Pt_Trace")) return;
     dof->focalLength = gdof.focalLength;                 /* DofUpdate, path_tracer.c:2485-2503 */
     ms_counters.trace++;
-    /* the reference's callers read the host images right after Pt_Trace (render_system.c:306-352) */
-    const bool aovs = ms_config.downloadAovs != 0;
-    ok(pimgpu_trace_download(ms_traces[slot].gpu, &trace->color->x, aovs ? &trace->albedo->x : NULL, aovs ? &trace->normal->x : NULL), "Pt_Trace");
 }
 
 void PtTrace_DownloadAovs(PtTrace* trace)

@@ -99,3 +99,41 @@ def test_trace_rays_and_raygen_bit_exact():
     assert_bits_equal(dg, do, "directions")
     assert_bits_equal(cg, co, "colors")
     g.close()
+
+
+@pytest.mark.parametrize("shares", ["1", "3", "8"])
+def test_trace_image_host_equals_trace_and_download(shares):
+    """pimgpu_trace_image_host (Pt_Trace as its callers use it): the pixels traced in shares, each share's part of the images
+    copied home under the next share's tracing -- the images, the statistics and the autofocus state of pimgpu_trace_image +
+    pimgpu_trace_download, bit for bit, whatever the number of shares (and those are checked against the oracle above)"""
+    gpu_init()
+    W, H = 200, 120
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    cam = scenes.camera((0.0, -2.0, 4.5), (0.0, -0.4, -1.0))
+    ga, gb = api.Scene(sc.desc), api.Scene(sc.desc)
+    ta, tb = api.Trace(W, H), api.Trace(W, H)
+    da, db = scenes.default_dof(), scenes.default_dof()
+    host = [np.full((W * H, 3), np.nan, np.float32) for _ in range(3)]
+    old = {k: os.environ.get(k) for k in ("PIMGPU_HOST_SHARES", "PIMGPU_HOST_SHARE_MIN")}
+    os.environ["PIMGPU_HOST_SHARES"] = shares; os.environ["PIMGPU_HOST_SHARE_MIN"] = "2048"
+    try:
+        for s in range(3):
+            p = scenes.trace_params(s, seed=5, max_bounces=6)
+            ta.trace(ga, cam, da, p)
+            tb.trace_to_host(gb, cam, db, p, host[0], host[1], host[2])
+            sa, sb = ta.stats(), tb.stats()
+            assert (sa.extensionRays, sa.shadowRays, sa.otherRays, sa.paths) == (sb.extensionRays, sb.shadowRays, sb.otherRays, sb.paths)
+            assert da.focalLength == db.focalLength
+            ref = ta.download()
+            for name, a, b in zip(("color", "albedo", "normal"), ref, host):
+                assert_bits_equal(b, a, f"{name} frame {s}")
+            for name, a, b in zip(("color", "albedo", "normal"), ref, tb.download()):
+                assert_bits_equal(b, a, f"device {name} frame {s}")
+        la, lb = ga.download_lights(), gb.download_lights()
+        for k in ("live", "pdf", "cdf"):
+            assert_bits_equal(lb[k], la[k], k)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    ta.close(); tb.close(); ga.close(); gb.close()
