@@ -1040,6 +1040,37 @@ static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
     return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;
 }
 
+/* the block a call leaves for the host (PathGroup::devBack -> hostBack): three separate copies from pageable memory were three
+ * host round trips with the GPU idle in between (25 us each: 5 % of a Cornell 1080p sample) */
+struct ReadBack { unsigned long long stats[8]; int32_t counters[64]; uint32_t traceStatus; float focal; unsigned long long prof[10]; };
+
+__global__ void k_collect(ReadBack* __restrict__ out, const unsigned long long* __restrict__ stats, const int32_t* __restrict__ counters,
+    uint32_t* __restrict__ status)
+{
+    const int i = threadIdx.x;
+    if (i < 8) out->stats[i] = stats[i];
+    if (i < 64) out->counters[i] = counters[i];
+    if (i < 10) out->prof[i] = stats[8 + i];
+    if (i == 0)
+    {
+        const uint32_t st = status[0];
+        out->traceStatus = st;
+        if (st & 1u) status[0] = st & ~1u;         /* reported once: cleared so that it cannot be blamed on the next call */
+        out->focal = __uint_as_float(status[20]);
+    }
+}
+
+/* the start of a call: queue length, counters and statistics (one launch instead of a copy from the host and a fill) */
+__global__ void k_begin(int32_t* __restrict__ counters, unsigned long long* __restrict__ stats, int32_t n)
+{
+    const int i = threadIdx.x;
+    if (i < 64) counters[i] = i == 0 ? n : 0;
+    if (i < 32) stats[i] = 0ull;
+}
+
+/* DofUpdate's ray (pt.c:2485-2496) written where the traversal launch reads it */
+__global__ void k_set_ray(float4* __restrict__ o, float4* __restrict__ d, float4 ro, float4 rd) { if (threadIdx.x == 0) { o[0] = ro; d[0] = rd; } }
+
 hipEvent_t PathGroup::take_event()
 {
     if (eventsUsed == eventPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; eventPool.push_back(e); }
@@ -1062,6 +1093,8 @@ int Library::ensure_group(int gi)
     }
     PT_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
     PT_HIP(hipEventCreateWithFlags(&g.stagger, hipEventDisableTiming));
+    PT_HIP(hipMalloc(&g.devBack, sizeof(ReadBack)));
+    PT_HIP(hipHostMalloc(&g.hostBack, sizeof(ReadBack), hipHostMallocDefault));
     return PIMGPU_OK;
 }
 
@@ -1075,6 +1108,8 @@ void Library::release_groups()
         if (g.done) hipEventDestroy(g.done);
         if (g.stagger) hipEventDestroy(g.stagger);
         for (hipEvent_t e : g.eventPool) hipEventDestroy(e);
+        if (g.devBack) hipFree(g.devBack);
+        if (g.hostBack) hipHostFree(g.hostBack);
         if (gi > 0) { hipStreamSynchronize(g.stream); hipStreamDestroy(g.stream); hipFree(g.counters); hipFree(g.stats); g.ownTrace.release(); }
         g = PathGroup();
     }
@@ -1093,13 +1128,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     const int32_t tailBounce = tail_policy(g, n, bounceLimit);
     g.first = first; g.n = n; g.wavefrontBounces = 0; g.tailBounce = -1; g.events.clear(); g.eventsUsed = 0;
     { int rcT = g.trace->ensure(); if (rcT) return rcT; }      /* the spill area behind the kernels' traversal stacks: gridBlocks * 256 lanes */
-    int32_t init[64] = {}; init[0] = n;
-    PT_HIP(hipMemcpyAsync(g.counters, init, sizeof(init), hipMemcpyHostToDevice, st));
-#ifdef PT_TAIL_PROF
-    PT_HIP(hipMemsetAsync(g.stats, 0, 256, st));
-#else
-    PT_HIP(hipMemsetAsync(g.stats, 0, 64, st));
-#endif
+    k_begin<<<1, 64, 0, st>>>(g.counters, g.stats, n);
     const int blocks = (int)std::min<int64_t>((int64_t)g_lib.cuCount * (2048 / kShadeThreads), ((int64_t)n + kShadeThreads - 1) / kShadeThreads);
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1185,26 +1214,21 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
 static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceMsOut)
 {
     hipStream_t st = g.stream;
-    unsigned long long hs[8];
-    int32_t counts[64];
-    PT_HIP(hipMemcpyAsync(hs, g.stats, sizeof(hs), hipMemcpyDeviceToHost, st));
-    PT_HIP(hipMemcpyAsync(counts, g.counters, sizeof(counts), hipMemcpyDeviceToHost, st));
     /* the batched traversal launches report a full stack in their own status word (trace.hip), the stages and the tail
-     * kernel in stats[4]: both end the call with PIMGPU_E_LIMIT, and the word is cleared so that it cannot be blamed on
-     * the next intersect call */
-    uint32_t traceStatus = 0;
-    PT_HIP(hipMemcpyAsync(&traceStatus, g.trace->status, sizeof(traceStatus), hipMemcpyDeviceToHost, st));
-#ifdef PT_TAIL_PROF
-    unsigned long long prof[10];
-    PT_HIP(hipMemcpyAsync(prof, g.stats + 8, sizeof(prof), hipMemcpyDeviceToHost, st));
-#endif
+     * kernel in stats[4]: both end the call with PIMGPU_E_LIMIT */
+    k_collect<<<1, 64, 0, st>>>((ReadBack*)g.devBack, g.stats, g.counters, g.trace->status);
+    PT_HIP(hipMemcpyAsync(g.hostBack, g.devBack, sizeof(ReadBack), hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
+    const ReadBack& rb = *(const ReadBack*)g.hostBack;
+    unsigned long long hs[8]; memcpy(hs, rb.stats, sizeof(hs));
+    const int32_t* counts = rb.counters;
+    if (rb.traceStatus & 1u) hs[4] |= 1ull;
 #ifdef PT_TAIL_PROF
+    const unsigned long long* prof = rb.prof;
     if (prof[4]) fprintf(stderr, "tailprof wave-bounces %llu | us per wave-bounce: ext %.1f stageA %.1f nee %.1f stageB %.1f | trips of the wave per walk: ext %.1f nee %.1f\n",
         prof[4], prof[0] * 0.01 / prof[4], prof[1] * 0.01 / prof[4], prof[2] * 0.01 / prof[4], prof[3] * 0.01 / prof[4],
         (double)prof[6] / prof[4], (double)prof[7] / prof[4]);
 #endif
-    if (traceStatus & 1u) { PT_HIP(hipMemsetAsync(g.trace->status, 0, 4, st)); hs[4] |= 1ull; }
     float clsMs[4] = { 0.0f, 0.0f, 0.0f, 0.0f }; int32_t traceLaunches = 0;
     for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.t0, e.t1); clsMs[e.cls] += ms; if (e.cls == 0) ++traceLaunches; }
     const float traceMs = clsMs[0];
@@ -1396,8 +1420,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     {
         const v4 fwd = quat_fwd(rot);
         const float4 ro = make_float4(eye.x, eye.y, eye.z, 0.0f), rd = make_float4(fwd.x, fwd.y, fwd.z, PT_RCP_EPS);
-        PT_HIP(hipMemcpyAsync(w.extO[0], &ro, sizeof(ro), hipMemcpyHostToDevice, st));
-        PT_HIP(hipMemcpyAsync(w.extD[0], &rd, sizeof(rd), hipMemcpyHostToDevice, st));
+        k_set_ray<<<1, 64, 0, st>>>(w.extO[0], w.extD[0], ro, rd);
         if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[0], w.extD[0], w.extHit, 1, nullptr, st))) return rc;
         focalDev = (float*)g_lib.trace.status + 20;                               /* spare words of the status block */
         const float tt = 1.0f - pl_expf(-p->frameDt * dof->autoFocusSpeed);
@@ -1448,11 +1471,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
             k_resolve_image<<<(count + 255) / 256, 256, 0, s>>>(w.results + first, pixelBegin + first, count, p->sampleWeight, t->color, t->albedo, t->normal);
             PT_HIP(hipEventRecord(g.done, s));
             ++used;
-            if (last)
-            {
-                hipEventRecord(e1, s);
-                if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s);
-            }
+            if (last) hipEventRecord(e1, s);
             /* this share's pixels go home while the next share is traced */
             const size_t off = (size_t)(pixelBegin + first) * 3, bytes = sizeof(float) * 3 * (size_t)count;
             if (hostColor) hipMemcpyAsync(hostColor + off, t->color + off, bytes, hipMemcpyDeviceToHost, s);
@@ -1473,7 +1492,6 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     if (n > 0) k_init_image<<<(n + 255) / 256, 256, 0, st>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
     if ((rc = integrate_image(scene, n, p->maxBounces, &stats, p->updateDists >= 0 ? &traceMs : nullptr, [&](hipStream_t s)
         { k_resolve_image<<<(n + 255) / 256, 256, 0, s>>>(w.results, pixelBegin, n, p->sampleWeight, t->color, t->albedo, t->normal); hipEventRecord(e1, s);
-          if (focalDev) hipMemcpyAsync(&focalHost, focalDev, sizeof(float), hipMemcpyDeviceToHost, s);
           if (toHost)
           {
               const size_t off = (size_t)pixelBegin * 3, bytes = sizeof(float) * 3 * (size_t)n;
@@ -1483,6 +1501,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
           } }))) return rc;
     }
     PT_HIP(hipEventSynchronize(e1));
+    if (focalDev) focalHost = ((const ReadBack*)g_lib.groups[0].hostBack)->focal;  /* came home with group 0's statistics (k_collect) */
     dof->focalLength = focalHost;                                                  /* DofUpdate updates the caller's struct */
     float totalMs = 0.0f; hipEventElapsedTime(&totalMs, e0, e1);
     stats.otherRays += otherRays;

@@ -95,6 +95,9 @@ struct PathGroup
     int32_t* counters = nullptr; unsigned long long* stats = nullptr;      /* device, 256 bytes each */
     TraceResources* trace = nullptr; TraceResources ownTrace;
     hipEvent_t done = nullptr, stagger = nullptr;
+    /* what the host reads after a call -- statistics, queue lengths, the traversal status word, the frame's focal length -- is
+     * gathered by one small kernel (k_collect) and comes home in ONE copy into page-locked memory: integrate.hip, ReadBack */
+    void* devBack = nullptr; void* hostBack = nullptr;
     /* queue length at the start of each wavefront bounce of the previous integrate call (host copy): the tail policy */
     int32_t history[64] = {}; int32_t historyBounces = 0; int64_t historyN = -1;
     /* the call in flight */
