@@ -137,3 +137,20 @@ def test_trace_image_host_equals_trace_and_download(shares):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     ta.close(); tb.close(); ga.close(); gb.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 65, 700])
+def test_trace_rays_small_batches_bit_exact(n):
+    """batches that leave most lanes of a wave (or all but one) without a path: in the one-launch integrator those lanes only
+    help with the other lanes' rays (traverse_coop) -- same results as the oracle's scalar Pt_TraceRay"""
+    gpu_init()
+    sc = scenes.cornell_box("spheres", sky_size=16, emissive_attempts=64)
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    ro, rd = scenes.random_rays(sc, n, seed=100 + n)
+    for k in range(2):
+        rg = g.trace_rays(ro, rd, sampleIndex=k, seed=9, maxBounces=7)
+        ro_ = o.trace_rays(ro, rd, sampleIndex=k, seed=9, maxBounces=7)
+        for name in ("color", "albedo", "normal"):
+            assert_bits_equal(rg[name], ro_[name], f"{name} call {k}")
+    g.close()
