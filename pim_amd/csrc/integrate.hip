@@ -251,7 +251,7 @@ struct CameraArgs
     PimDofInfo dof;
     int32_t width, height;
     uint32_t sampleIndex, seed;
-    const float* focalDev;          /* non-null: dof.focalLength of this frame, left on the device by k_focus_update */
+    const float* focalDev;          /* non-null: dof.focalLength of this frame, left on the device by k_focus */
     int32_t pixelBegin, pixelCount; /* the band of pixels this launch renders (multi-device: rows of the image) */
     int32_t slotBegin;              /* path slot of the band's first pixel (shares of an image: pimgpu_trace_image_host) */
 };
@@ -272,16 +272,6 @@ __device__ __forceinline__ void CalculateDof(Ctx& ctx, const PimDofInfo& dof, v4
     const v4 aperturePos = f4_add(*ro, f4_add(f4_muls(right, offset.x), f4_muls(up, offset.y)));
     *ro = aperturePos;
     *rd = f4_normalize3(f4_sub(focusPos, aperturePos));
-}
-
-/* DofUpdate's smoothing (pt.c:2497-2501) on the device: the autofocus ray's hit stays in HBM, so the frame needs no host
- * round trip between that ray and the camera rays; the host reads the new focal length back with the statistics */
-__global__ void k_focus_update(const DHit* __restrict__ hit, float focalLength, float tt, float* __restrict__ focalDev)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const DHit h = hit[0];
-    if (h.prim >= 0 && h.t > 0.0f) focalLength = f1_lerp(focalLength, h.t, tt);
-    *focalDev = focalLength;
 }
 
 /* TraceFn up to Pt_TraceRay, pt.c:2514-2545 */
@@ -917,6 +907,31 @@ __global__ __launch_bounds__(kTailThreads, OCC) void k_tail(DScene s, StageArgs 
     if (overflow) atomicOr((unsigned int*)&a.stats[4], 1u);
 }
 
+/* DofUpdate, pt.c:2485-2503: the autofocus ray and the smoothing of the focal length in one launch of one wave.  The ray is
+ * walked by all 64 lanes (traverse_coop: ~12 trips instead of the ~50 dependent steps of a lone lane -- 67 -> 25 us on the
+ * 1 M-triangle scene); the frame's focal length stays on the device for k_init_image and comes home with the statistics. */
+__global__ __launch_bounds__(64) void k_focus(DBvh bvh, float4 ro, float4 rd, float focalLength, float tt, float* __restrict__ focalDev,
+    unsigned long long* __restrict__ spill, uint32_t* __restrict__ status, int32_t stackCap)
+{
+    __shared__ unsigned long long sStack[PT_STACK_LDS * 64];
+    __shared__ unsigned long long sCoop[2 * 64];
+    __shared__ int sList[64];
+    LdsStack st;
+    st.lds = (lds_u64*)(sStack + threadIdx.x); st.ldsStride = 64;
+    st.spillStride = 64; st.spill = (glb_u64*)(spill + threadIdx.x);
+    st.sp = 0; st.cap = stackCap;
+    CoopArea ca;
+    ca.best = (lds_u64*)sCoop; ca.uv = (lds_u64*)(sCoop + 64); ca.list = (lds_i32*)sList;
+    bool overflow = false;
+    const DHit h = traverse_coop(bvh, threadIdx.x == 0, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, ro.w, rd.w, st, overflow, ca);
+    if (overflow) atomicOr(status, 1u);
+    if (threadIdx.x == 0)
+    {
+        if (h.prim >= 0 && h.t > 0.0f) focalLength = f1_lerp(focalLength, h.t, tt);
+        *focalDev = focalLength;
+    }
+}
+
 /* paths still queued when the host stops the loop (bounce limit reached inside shade_b never leaves any;
  * this covers maxBounces == 0 style early stops): not needed -- shade_b finishes every path at the limit. */
 
@@ -1079,9 +1094,6 @@ __global__ void k_begin(int32_t* __restrict__ counters, unsigned long long* __re
     if (i < 64) counters[i] = i == 0 ? n : 0;
     if (i < 32) stats[i] = 0ull;
 }
-
-/* DofUpdate's ray (pt.c:2485-2496) written where the traversal launch reads it */
-__global__ void k_set_ray(float4* __restrict__ o, float4* __restrict__ d, float4 ro, float4 rd) { if (threadIdx.x == 0) { o[0] = ro; d[0] = rd; } }
 
 hipEvent_t PathGroup::take_event()
 {
@@ -1432,11 +1444,10 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     {
         const v4 fwd = quat_fwd(rot);
         const float4 ro = make_float4(eye.x, eye.y, eye.z, 0.0f), rd = make_float4(fwd.x, fwd.y, fwd.z, PT_RCP_EPS);
-        k_set_ray<<<1, 64, 0, st>>>(w.extO[0], w.extD[0], ro, rd);
-        if ((rc = trace_closest(scene->d.bvh, &g_lib.trace, w.extO[0], w.extD[0], w.extHit, 1, nullptr, st))) return rc;
+        if ((rc = g_lib.trace.ensure())) return rc;
         focalDev = (float*)g_lib.trace.status + 20;                               /* spare words of the status block */
         const float tt = 1.0f - pl_expf(-p->frameDt * dof->autoFocusSpeed);
-        k_focus_update<<<1, 64, 0, st>>>(w.extHit, dof->focalLength, tt, focalDev);
+        k_focus<<<1, 64, 0, st>>>(scene->d.bvh, ro, rd, dof->focalLength, tt, focalDev, g_lib.trace.spill, g_lib.trace.status, trace_stack_cap());
         otherRays = 1;
     }
     CameraArgs c;
