@@ -426,6 +426,15 @@ struct CoopArea
 #define PT_STEAL_MIN 8      /* lanes out of work before the wave spends a trip on handing work over */
 #endif
 
+/* lanes of one wave hand data to each other through LDS: the hardware runs a wave's LDS instructions in order, this keeps the
+ * compiler from moving them across the hand-over point (a wavefront-scope fence emits no cache operation) */
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 __device__ __forceinline__ int wave_rank(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 template <bool COUNT = false>
@@ -458,7 +467,7 @@ __device__ __forceinline__ DHit traverse_coop(const DBvh& bvh, bool valid, float
                 const int nGivers = (int)__popcll(givers), nIdle = (int)__popcll(idle);
                 const int rankG = wave_rank(givers), rankI = wave_rank(idle);
                 if (giver) ca.list[rankG] = lane;
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
                 const bool asks = cur == PT_BVH_EMPTY;
                 const int from = asks ? ca.list[rankI % nGivers] : lane;
                 const int depth = rankI / nGivers;
@@ -485,7 +494,7 @@ __device__ __forceinline__ DHit traverse_coop(const DBvh& bvh, bool valid, float
                     const int askers = rankG < nIdle ? (nIdle - rankG + nGivers - 1) / nGivers : 0;      /* idle lanes i with i mod givers == rankG */
                     base += askers < avail ? askers : avail;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
             }
         }
 #if PT_COOP_LEAF_VOTE > 0
@@ -557,7 +566,7 @@ __device__ __forceinline__ DHit traverse_coop(const DBvh& bvh, bool valid, float
                 /* publish: the minimum over everything found for this owner; the lane whose key stands writes u, v */
                 const unsigned long long key = ((unsigned long long)__float_as_uint(h.t) << 32) | (unsigned long long)(uint32_t)h.prim;
                 if (h.prim >= 0) __hip_atomic_fetch_min((unsigned long long*)(ca.best + owner), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
                 if (h.prim >= 0 && ca.best[owner] == key) ca.uv[owner] = ((unsigned long long)__float_as_uint(h.v) << 32) | (unsigned long long)__float_as_uint(h.u);
             }
             if (next == PT_BVH_EMPTY)
@@ -573,7 +582,7 @@ __device__ __forceinline__ DHit traverse_coop(const DBvh& bvh, bool valid, float
             cur = next;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const unsigned long long k = ca.best[lane];
     DHit h; h.prim = -1; h.t = tFar; h.u = 0.0f; h.v = 0.0f;
     if ((uint32_t)k != 0x7fffffffu)
