@@ -978,31 +978,29 @@ __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ 
  * (Launched with 64 threads; the bound of 128 only keeps the compiler from proving the address uniform and moving the loads
  * to the scalar unit, whose loads cannot be waited for one by one.)
  */
-static constexpr int kSumRing = 48;
+static constexpr int kSumRing = 48;         /* float4 loads in flight */
+static constexpr int kSumBody = 4 * kSumRing;   /* float4 per pass of the loop: straight-line code, nothing carried around the back edge */
 __global__ __launch_bounds__(128) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
 {
     const float4* __restrict__ t4 = (const float4*)terms + (threadIdx.x >> 6);       /* == terms: the launch has one wave */
     const int32_t n4 = len >> 2;
     float acc = 0.0f;
-    float4 ring[kSumRing];
     int32_t i = 0;
-    if (n4 >= kSumRing)
+    /* One pass: kSumRing loads up front (their latency is paid once per pass, ~600 of ~3700 cycles), then every group of four
+     * additions is followed by the reload of its registers for 48 groups later.  The ring is NOT carried around the loop: carried,
+     * the register allocator rotated it with one v_mov per v_add on the chain's own issue slots (5.5 ns per term). */
+    for (; i + kSumBody <= n4; i += kSumBody)
     {
+        float4 ring[kSumRing];
 #pragma unroll
-        for (int k = 0; k < kSumRing; ++k) ring[k] = t4[k];
-        for (; i + 2 * kSumRing <= n4; i += kSumRing)
+        for (int k = 0; k < kSumRing; ++k) ring[k] = t4[i + k];
+#pragma unroll
+        for (int k = 0; k < kSumBody; ++k)
         {
-#pragma unroll
-            for (int k = 0; k < kSumRing; ++k)
-            {
-                const float4 v = ring[k];
-                ring[k] = t4[i + kSumRing + k];
-                acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
-            }
+            const float4 v = ring[k % kSumRing];
+            acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
+            if (k + kSumRing < kSumBody) ring[k % kSumRing] = t4[i + k + kSumRing];
         }
-#pragma unroll
-        for (int k = 0; k < kSumRing; ++k) { const float4 v = ring[k]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
-        i += kSumRing;
     }
     for (int32_t j = i * 4; j < len; ++j) acc = acc + terms[j + (threadIdx.x >> 6)];
     if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(acc) : acc;
