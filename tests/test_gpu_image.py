@@ -154,3 +154,15 @@ def test_trace_rays_small_batches_bit_exact(n):
         for name in ("color", "albedo", "normal"):
             assert_bits_equal(rg[name], ro_[name], f"{name} call {k}")
     g.close()
+
+
+@pytest.mark.parametrize("ntri", [0, 1, 5])
+def test_tiny_scenes_render_bit_exact(ntri):
+    """no triangle at all, a single-leaf tree and the smallest real tree under an open sky, through the one-launch integrator
+    and through two wavefront bounces: every ray misses or meets the same few triangles"""
+    full = scenes.cornell_box()
+    b = scenes.SceneBuilder(seed=1, sky_size=8, emissive_attempts=8)
+    m = b.material((0.6, 0.5, 0.4, 1.0), (0.7, 1.0, 0.0, 0.0))
+    if ntri:
+        b.add_arrays(full.positions[:ntri * 3], full.normals[:ntri * 3], full.uvs[:ntri * 3], m)
+    _render_both(b.build(), 64, 36, 2, 4)
