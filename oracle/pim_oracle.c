@@ -213,6 +213,7 @@ static OrcHit closest_bvh(const OrcScene* s, v4 ro, v4 rd, float tNear, float tF
 {
     OrcRayPre r; ray_pre(&r, ro, rd);
     OrcHit h; h.prim = -1; h.t = tFar; h.u = h.v = 0.0f;
+    if (s->vertCount < 3) return h;            /* no triangle: the root is a box turned inside out with no children to follow */
     const float inv[3] = { 1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z };
     float sceneMaxAbs = 0.0f;
     for (int a = 0; a < 3; ++a) sceneMaxAbs = fmaxf(sceneMaxAbs, fmaxf(fabsf(s->nodes[0].lo[a]), fabsf(s->nodes[0].hi[a])));
