@@ -12,7 +12,13 @@ from tests.gpu_util import assert_bits_equal
 from tests.util import OracleScene
 
 
+def stage(name):
+    """progress on stderr: a process that dies between two of these has said where"""
+    print(f"[worker] {name}", file=sys.stderr, flush=True)
+
+
 def main(n):
+    stage("init")
     api.init_devices([0] * n)
     lib = api.load_library()
     assert lib.pimgpu_device_count() == n
@@ -23,6 +29,7 @@ def main(n):
     for k in ("vertToEmit", "emitToVert", "cellLength", "pdf", "cdf", "live"):
         assert_bits_equal(gl[k], ol[k], k)
 
+    stage("image")
     # image: bands of rows, one per context; 50 rows do not divide by 3
     W, H = 96, 50
     t = api.Trace(W, H)
@@ -45,6 +52,7 @@ def main(n):
         assert_bits_equal(gl[k], ol[k], k + " after 4 frames")      # the replicas' histograms were summed before every UpdateDists
     assert (gl["live"] > 0).any()
 
+    stage("raygen")
     # the entry points that run on the first device see (and feed) the same histograms
     origin = np.array([0.5, -1.0, 0.25, 0.0], np.float32)
     cg, dgn = g.raygen(origin, 20000, sampleIndex=1, seed=3, maxBounces=4)
@@ -53,6 +61,7 @@ def main(n):
     t.trace(g, cam, dg, scenes.trace_params(4, seed=17, max_bounces=5)); o.trace_image(img, W, H, cam, do, scenes.trace_params(4, seed=17, max_bounces=5))
     assert_bits_equal(t.download()[0], img[0], "color after raygen")
 
+    stage("lightmap bake")
     # lightmap bake: 64x64 tiles round-robin over the contexts; 96^2 pages = 2x2 tiles with a ragged edge
     S = 96
     pages = scenes.lightmap_pages_for(sc, S, 3.0, max_pages=2)
@@ -68,6 +77,7 @@ def main(n):
     for a, b in zip(pg, po):
         assert_bits_equal(a, b, "sub-range pages")
 
+    stage("resident lightmaps")
     # the same with pages resident in HBM: every context keeps a replica and bakes its tiles of it, the download merges them
     hs = [p.copy() for p in pages]; po2 = [p.copy() for p in pages]
     lm = api.LightmapSet(len(pages), S)
@@ -80,6 +90,7 @@ def main(n):
         assert_bits_equal(a, b, "resident pages")
     lm.close()
 
+    stage("rebuild, shutdown, second list")
     g.rebuild_bvh()
     ro, rd = scenes.random_rays(sc, 5000, seed=2)
     assert g.intersect(ro, rd).tobytes() == o.intersect(ro, rd).tobytes()
@@ -90,7 +101,8 @@ def main(n):
     sc2 = scenes.cornell_box()
     g = api.Scene(sc2.desc); g.close()
     api.shutdown()
-    print(f"MULTI-DEVICE OK {n}")
+    stage("done")
+    print(f"MULTI-DEVICE OK {n}", flush=True)
 
 
 if __name__ == "__main__":

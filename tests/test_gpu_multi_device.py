@@ -15,5 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("n", [1, 2, 3])
 def test_device_list_matches_oracle(n):
-    run = subprocess.run([sys.executable, "-m", "tests.multi_device_worker", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=280)
-    assert run.returncode == 0 and f"MULTI-DEVICE OK {n}" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
+    run = subprocess.run([sys.executable, "-u", "-X", "faulthandler", "-m", "tests.multi_device_worker", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    ok = run.returncode == 0 and f"MULTI-DEVICE OK {n}" in run.stdout
+    assert ok, run.stdout[-3000:] + run.stderr[-3000:]
