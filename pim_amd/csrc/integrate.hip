@@ -1506,7 +1506,8 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
             traceMs += ms;
             if (rc == PIMGPU_OK) rc = r;
         }
-        if (rc) { for (int k = 0; k < used; ++k) hipStreamSynchronize(g_lib.groups[k].stream); return rc; }
+        /* on failure also the share whose enqueue failed: its stream may hold launches that use the work buffers */
+        if (rc) { for (int k = 0; k <= used && k < shares; ++k) hipStreamSynchronize(g_lib.groups[k].stream); return rc; }
     }
     else
     {
