@@ -355,10 +355,13 @@ int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDe
 int pimgpu_trace_copy_dev(const PimTrace* trace, void* colorDst, void* albedoDst, void* normalDst);
 /* CalcStdDev (render_system.c:1374-1394) on the device colour buffer */
 int pimgpu_trace_stddev(const PimTrace* trace, float* meanOut, float* stddevOut);
-/* NO COUNTERPART IN THE REFERENCE.  pimgpu_trace_stddev for callers that cannot allocate (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc): same result bit for bit, but the per-pixel terms live in a
- * file-scope device array of the library (31.6 MiB per GPU, held until the process ends) instead of a work buffer grown
- * on demand.  Limit: width*height <= 3840*2160, else PIMGPU_E_LIMIT.  Calls that overlap on one GPU share the array and race. */
+/* NO COUNTERPART IN THE REFERENCE.  pimgpu_trace_stddev for callers that cannot allocate (tight serving loops, harnesses that
+ * forbid hipMalloc after set-up): same result bit for bit, but the per-pixel terms live in a file-scope device array of the
+ * library (31.6 MiB per GPU, held until the process ends) instead of a work buffer grown on demand, and the two floats come
+ * back through a page-locked block made at pimgpu_init.  The call is synchronous (a device-to-host copy and a stream wait), so
+ * it cannot run under HIP graph capture.  Limit: width*height <= 3840*2160, else PIMGPU_E_LIMIT.  The array belongs to the GPU:
+ * all contexts on one GPU (a device listed twice in pimgpu_init_devices) and all concurrent callers share it, so calls that
+ * overlap on one GPU race. */
 int pimgpu_trace_stddev_noalloc(const PimTrace* trace, float* meanOut, float* stddevOut);
 /* statistics of the last pimgpu_trace_image call: rays traced (extension, shadow, other), bounces */
 typedef struct PimTraceStats
@@ -368,7 +371,9 @@ typedef struct PimTraceStats
     uint64_t otherRays;         /* media NEE + refraction thickness + autofocus */
     uint64_t paths;
     int32_t  bounces;           /* wavefront bounce iterations launched (two traversal launches each) before the tail kernel */
-    float    traceMs;           /* device time inside the traversal kernels */
+    float    traceMs;           /* device time inside the traversal kernels.  The per-kernel times of this struct come from events attached
+                                   to the dispatches; a call times its first 256 dispatches (36 wavefront bounces) and launches the rest
+                                   plain, so for deeper roulette-only calls without the tail kernel they are lower bounds */
     float    totalMs;           /* device time of the whole call */
     uint64_t tailRays;          /* of the rays above: traced inside the tail kernel, which finishes the short queues of deep
                                    bounces in one launch (not by the batched traversal launches traceMs covers) */

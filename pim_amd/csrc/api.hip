@@ -12,6 +12,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <thread>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 
 namespace pt {
 
@@ -194,25 +197,66 @@ int scene_update_dists_all(PimScene* scene)
 
 using namespace pt;
 
+/*
+ * Diagnostics of the library's first calls (host code only).  PIMGPU_SEGV_BACKTRACE=1: a process that dies of SIGSEGV /
+ * SIGBUS / SIGABRT / SIGFPE inside the library or the HIP runtime under it prints its NATIVE frames to stderr before the
+ * default action runs (Python's faulthandler only names the ctypes call); PIMGPU_INIT_TRACE=1: one stderr line before every
+ * HIP call of pimgpu_init_devices, so that a hang or a fault names the call it happened in.
+ */
+static void fault_backtrace(int sig)
+{
+    static const char head[] = "[pimgpu] fatal signal, native frames:\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+static void install_fault_backtrace()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("PIMGPU_SEGV_BACKTRACE");
+    if (!e || !*e || *e == '0') return;
+    void* warm[4]; (void)backtrace(warm, 4);          /* loads libgcc's unwinder now: not from inside the handler */
+    struct sigaction sa; memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = fault_backtrace; sa.sa_flags = SA_NODEFER | SA_RESETHAND;
+    sigemptyset(&sa.sa_mask);
+    const int sigs[] = { SIGSEGV, SIGBUS, SIGABRT, SIGFPE };
+    for (int sgn : sigs) sigaction(sgn, &sa, nullptr);
+}
+
+static bool init_trace_on() { static const bool on = [] { const char* e = getenv("PIMGPU_INIT_TRACE"); return e && *e && *e != '0'; }(); return on; }
+#define INIT_TRACE(...) do { if (init_trace_on()) { fprintf(stderr, "[pimgpu init] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 extern "C" {
 
 /* one context: stream, traversal resources, scratch address; the device is current */
 static int init_context(Library& L, int device)
 {
     hipDeviceProp_t prop;
+    INIT_TRACE("hipGetDeviceProperties(%d)", device);
     PT_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     {
         set_error("device %d is %s; libpimgpu is built for gfx950 only", device, prop.gcnArchName);
         return PIMGPU_E_DEVICE;
     }
+    INIT_TRACE("hipStreamCreateWithFlags");
     PT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     L.device = device;
     L.cuCount = prop.multiProcessorCount;
+    INIT_TRACE("traversal resources (occupancy query, spill hipMalloc)");
     int rc = L.trace.ensure();
     if (rc) return rc;
+    PT_HIP(hipHostMalloc((void**)&L.smallBack, 64, hipHostMallocDefault));
+    INIT_TRACE("hipGetSymbolAddress(scratch)");
     if ((rc = stddev_scratch_setup(device))) return rc;
     L.initialised = true;
+    INIT_TRACE("context on device %d ready", device);
     return PIMGPU_OK;
 }
 
@@ -228,19 +272,23 @@ int pimgpu_init_devices(const int* devices, int deviceCount)
         return PIMGPU_E_STATE;
     }
     if (!devices || deviceCount < 1 || deviceCount > kMaxDevices) { set_error("init_devices: need 1..%d devices", kMaxDevices); return PIMGPU_E_INVALID; }
+    install_fault_backtrace();
     int count = 0;
+    INIT_TRACE("hipGetDeviceCount");
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return PIMGPU_E_DEVICE; }
     for (int i = 0; i < deviceCount; ++i)
         if (devices[i] < 0 || devices[i] >= count) { set_error("device %d out of range (have %d)", devices[i], count); return PIMGPU_E_INVALID; }
     int rc = PIMGPU_OK;
     for (int i = 0; i < deviceCount && !rc; ++i)
     {
+        INIT_TRACE("hipSetDevice(%d)", devices[i]);
         PT_HIP(hipSetDevice(devices[i]));
         rc = init_context(g_libs[i], devices[i]);
         /* replicas read each other's light histograms and image bands over xGMI */
         for (int k = 0; k < i && !rc; ++k)
             if (devices[k] != devices[i])
             {
+                INIT_TRACE("peer access %d <-> %d", devices[i], devices[k]);
                 hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("no peer access from device %d to %d", devices[i], devices[k]); rc = PIMGPU_E_DEVICE; }
                 (void)hipGetLastError();
@@ -254,7 +302,16 @@ int pimgpu_init_devices(const int* devices, int deviceCount)
     hipSetDevice(devices[0]);
     if (rc)
     {
-        for (int i = 0; i < deviceCount; ++i) if (g_libs[i].stream) { hipSetDevice(devices[i]); g_libs[i].trace.release(); hipStreamDestroy(g_libs[i].stream); g_libs[i] = Library(); }
+        for (int i = 0; i < deviceCount; ++i)
+            if (g_libs[i].stream)
+            {
+                hipSetDevice(devices[i]);
+                g_libs[i].trace.release();
+                if (g_libs[i].smallBack) hipHostFree(g_libs[i].smallBack);
+                hipStreamDestroy(g_libs[i].stream);
+                g_libs[i] = Library();
+            }
+        hipSetDevice(devices[0]);
         return rc;
     }
     g_libCount = deviceCount;
@@ -293,6 +350,7 @@ int pimgpu_shutdown(void)
         L.release_groups();
         L.work.release();
         L.trace.release();
+        if (L.smallBack) hipHostFree(L.smallBack);
         hipStreamDestroy(L.stream);
         L = Library();
     }
@@ -313,9 +371,13 @@ int pimgpu_work_counters(int enable, uint64_t* out)
     {
         uint64_t w[12] = {};
         PT_HIP(hipMemcpy(w, g_lib.trace.work, sizeof(w), hipMemcpyDeviceToHost));
-        if (w[2]) fprintf(stderr, "[trace diag] rays %llu  trips(wave) %llu  A-exec %llu  B-exec %llu  pop-iter(wave) %llu  pop-lanes %llu  | per 64 rays: trips %.1f A %.1f B %.1f popIter %.1f\n",
+        if (w[2]) fprintf(stderr, "[trace diag] rays %llu  trips(wave) %llu  A-exec %llu  B-exec %llu  pop-iter(wave) %llu  pop-lanes %llu  | per 64 rays: trips %.1f A %.1f B %.1f popIter %.1f"
+            " | lanes per A-exec %.1f, per B-exec %.1f | lane-trips: at a node %.3f, no ray %.3f, second leaf waiting %.3f, nothing in hand %.3f, first leaf only %.3f\n",
             (unsigned long long)w[2], (unsigned long long)w[4], (unsigned long long)w[5], (unsigned long long)w[6], (unsigned long long)w[7], (unsigned long long)w[8],
-            64.0 * w[4] / w[2], 64.0 * w[5] / w[2], 64.0 * w[6] / w[2], 64.0 * w[7] / w[2]);
+            64.0 * w[4] / w[2], 64.0 * w[5] / w[2], 64.0 * w[6] / w[2], 64.0 * w[7] / w[2],
+            (double)w[0] / (double)(w[5] ? w[5] : 1), (double)w[1] / (double)(w[6] ? w[6] : 1),
+            w[0] / (64.0 * w[4]), w[9] / (64.0 * w[4]), w[10] / (64.0 * w[4]), w[11] / (64.0 * w[4]),
+            1.0 - (double)(w[0] + w[9] + w[10] + w[11]) / (64.0 * w[4]));
     }
     PT_HIP(hipMemset(g_lib.trace.work, 0, 12 * sizeof(uint64_t)));
     g_lib.trace.counting = enable != 0;

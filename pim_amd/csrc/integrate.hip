@@ -1093,10 +1093,23 @@ __global__ void k_begin(int32_t* __restrict__ counters, unsigned long long* __re
     if (i < 32) stats[i] = 0ull;
 }
 
+/* Timing events are pooled, and the pool is BOUNDED: a call times its first kMaxTimedDispatches dispatches and launches the
+ * rest plain (a roulette-only call without the tail kernel is 666 bounces x 7 launches: unbounded, that was ~9 300 live HIP
+ * events per group, each holding a completion signal of the runtime, kept until pimgpu_shutdown).  After a call the pool
+ * shrinks back to kKeepEvents (integrate_finish).  The bench workloads (8 bounces: <= 60 dispatches) are timed in full. */
+static constexpr size_t kMaxTimedDispatches = 256, kKeepEvents = 128;
+
 hipEvent_t PathGroup::take_event()
 {
+    if (eventsUsed >= 2 * kMaxTimedDispatches) return nullptr;
     if (eventsUsed == eventPool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; eventPool.push_back(e); }
     return eventPool[eventsUsed++];
+}
+
+void PathGroup::trim_events()
+{
+    while (eventPool.size() > kKeepEvents) { hipEventDestroy(eventPool.back()); eventPool.pop_back(); }
+    eventsUsed = 0;
 }
 
 int Library::ensure_group(int gi)
@@ -1155,7 +1168,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     const int slowBlocks = std::max(1, blocks / 4);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     /* events attached to the dispatches themselves (no barrier packets, trace.hip): cls 0 traversal, 1 shade_a, 2 shade_b, 3 tail */
-    auto timed = [&](int cls) { t0 = t1 = nullptr; if (timeTrace) { t0 = g.take_event(); t1 = g.take_event(); if (t0 && t1) g.events.push_back({ cls, t0, t1 }); else t0 = t1 = nullptr; } };
+    auto timed = [&](int cls) { t0 = t1 = nullptr; if (timeTrace) { t0 = g.take_event(); t1 = t0 ? g.take_event() : nullptr; if (t0 && t1) g.events.push_back({ cls, t0, t1 }); else t0 = t1 = nullptr; } };
 #define PT_LAUNCH(kernel, grid, block, ...) do { if (t0 && t1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, t0, t1, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, __VA_ARGS__); } while (0)
     int rc = PIMGPU_OK;
@@ -1255,6 +1268,7 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     for (auto& e : g.events) { float ms = 0.0f; hipEventElapsedTime(&ms, e.t0, e.t1); clsMs[e.cls] += ms; if (e.cls == 0) ++traceLaunches; }
     const float traceMs = clsMs[0];
     g.events.clear();
+    g.trim_events();
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow (tree deeper than %d entries)", PT_STACK_MAX); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
      * what the history knew beyond its switch point. */
@@ -1420,7 +1434,7 @@ int pimgpu_trace_clear(PimTrace* t)
  * is copied to the host behind its resolve -- while the next share is being traced.  A path depends on nothing but its own
  * Prng stream and the scene, so the shares do not change a bit of the image (the groups of integrate_image, run in sequence). */
 static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p, int32_t pixelBegin, int32_t n,
-    float* hostColor = nullptr, float* hostAlbedo = nullptr, float* hostNormal = nullptr)
+    float* hostColor = nullptr, float* hostAlbedo = nullptr, float* hostNormal = nullptr, bool distsDone = false)
 {
     int rc = check_ready(); if (rc) return rc;
     memset(&t->stats, 0, sizeof(t->stats));
@@ -1431,7 +1445,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     if (!g_lib.frameBegin) { PT_HIP(hipEventCreate(&g_lib.frameBegin)); PT_HIP(hipEventCreate(&g_lib.frameEnd)); }
     hipEvent_t e0 = g_lib.frameBegin, e1 = g_lib.frameEnd;
     PT_HIP(hipEventRecord(e0, st));
-    if (p->updateDists) { if ((rc = update_dists(scene->d, st))) return rc; }      /* PtScene_Update, pt.c:1034 */
+    if (p->updateDists && !distsDone) { if ((rc = update_dists(scene->d, st))) return rc; }      /* PtScene_Update, pt.c:1034 */
 
     const v4 rot = f4_v(cam->rotation[0], cam->rotation[1], cam->rotation[2], cam->rotation[3]);
     const v4 eye = f4_v(cam->position[0], cam->position[1], cam->position[2], cam->position[3]);
@@ -1485,13 +1499,13 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
             hipStream_t s = g.stream;                                     /* share 0: the library's stream, with the set-up above */
             /* a share starts when the one before it has been resolved (unchained, the shares' launches interleave and all end together:
              * 3.2 instead of 2.8 ms at 1080p) */
-            if (k > 0) PT_HIP(hipStreamWaitEvent(s, g_lib.groups[k - 1].done, 0));
+            if (k > 0 && hipStreamWaitEvent(s, g_lib.groups[k - 1].done, 0) != hipSuccess) { set_error("trace_image: hipStreamWaitEvent failed"); rc = PIMGPU_E_DEVICE; break; }
             c.pixelBegin = pixelBegin + first; c.pixelCount = count; c.slotBegin = first;
             k_init_image<<<(count + 255) / 256, 256, 0, s>>>(w.ps, w.extO[0], w.extD[0], w.queue[0], c);
             if ((rc = integrate_enqueue(scene, g, first, count, p->maxBounces, timeTrace, -1))) break;
             k_resolve_image<<<(count + 255) / 256, 256, 0, s>>>(w.results + first, pixelBegin + first, count, p->sampleWeight, t->color, t->albedo, t->normal);
-            PT_HIP(hipEventRecord(g.done, s));
-            ++used;
+            ++used;                                                       /* from here on the share's stream holds work: it is drained below */
+            if (hipEventRecord(g.done, s) != hipSuccess) { set_error("trace_image: hipEventRecord failed"); rc = PIMGPU_E_DEVICE; break; }
             if (last) hipEventRecord(e1, s);
             /* this share's pixels go home while the next share is traced */
             const size_t off = (size_t)(pixelBegin + first) * 3, bytes = sizeof(float) * 3 * (size_t)count;
@@ -1546,12 +1560,13 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
      * one-device image bit for bit.  No exchange step here: every device copies its own band to the host (pimgpu_trace_download).
      */
     if (p->updateDists) { if ((rc = scene_update_dists_all(scene))) return rc; }
-    PimTraceParams q = *p; q.updateDists = 0;
+    const PimTraceParams q = *p;                          /* UpdateDists ran above (distsDone); the sign of updateDists still says "no per-dispatch timing" */
     PimDofInfo dofs[kMaxDevices];
     for (int i = 0; i < G; ++i) dofs[i] = *dof;
     rc = for_each_context(G, [&](int i) {
         int32_t r0, r1; band_of(t->height, i, G, &r0, &r1);
-        return trace_image_one(i == 0 ? scene : scene->peers[i], i == 0 ? t : t->peers[i], cam, &dofs[i], &q, r0 * t->width, (r1 - r0) * t->width);
+        return trace_image_one(i == 0 ? scene : scene->peers[i], i == 0 ? t : t->peers[i], cam, &dofs[i], &q, r0 * t->width, (r1 - r0) * t->width,
+            nullptr, nullptr, nullptr, true);
     });
     if (rc) return rc;
     *dof = dofs[0];                                       /* every context traced the same autofocus ray */
@@ -1686,8 +1701,11 @@ int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
 }
 
 /* pimgpu_trace_stddev without any allocation: the same two kernels per sum, their terms in this GPU's copy of the
- * file-scope `scratch` array (address taken at pimgpu_init).  No hipMalloc / hipFree / allocating routine is called.
- * Calls that overlap on one GPU share that array and race; nothing needs clearing (terms [0, len) are all rewritten). */
+ * file-scope `scratch` array (address taken at pimgpu_init).  No hipMalloc / hipFree / allocating routine is called; the two
+ * results come back through a page-locked block made at init.  The call copies to the host and waits for its stream, so it is
+ * NOT for use under graph capture.  The array belongs to the GPU, not to a context: every context on one GPU (a device listed
+ * twice) and every concurrent caller share it, so calls that overlap on one GPU race; nothing needs clearing (terms [0, len)
+ * are all rewritten). */
 int pimgpu_trace_stddev_noalloc(const PimTrace* t, float* meanOut, float* stddevOut)
 {
     int rc = check_ready(); if (rc) return rc;
@@ -1710,8 +1728,9 @@ int pimgpu_trace_stddev_noalloc(const PimTrace* t, float* meanOut, float* stddev
     k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
     k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
     PT_HIP(hipGetLastError());
-    float h[2];
-    PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
+    float* h = g_lib.smallBack;                             /* page-locked, made at pimgpu_init: the copy is not staged */
+    if (!h) { set_error("trace_stddev_noalloc: no read-back block (pimgpu_init)"); return PIMGPU_E_STATE; }
+    PT_HIP(hipMemcpyAsync(h, outDev, 2 * sizeof(float), hipMemcpyDeviceToHost, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));
     if (meanOut) *meanOut = h[0];
     if (stddevOut) *stddevOut = h[1];

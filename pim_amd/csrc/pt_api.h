@@ -106,7 +106,8 @@ struct PathGroup
     std::vector<Timed> events;
     std::vector<hipEvent_t> eventPool; size_t eventsUsed = 0;   /* timing events are made once and reused: creating and
                                                                     destroying 14 per frame was host time with the GPU idle */
-    hipEvent_t take_event();
+    hipEvent_t take_event();                                    /* nullptr once the call has timed kMaxTimedDispatches dispatches */
+    void trim_events();                                         /* after a call: the pool shrinks back to a few frames' worth */
 };
 static constexpr int kMaxGroups = 8;
 
@@ -119,6 +120,8 @@ struct Library
     TraceResources trace;
     WorkBuffers work;
     hipEvent_t frameBegin = nullptr, frameEnd = nullptr;     /* pimgpu_trace_image's totalMs */
+    float* smallBack = nullptr;                              /* 64 page-locked bytes made at init: where pimgpu_trace_stddev_noalloc's two floats land (a copy
+                                                                into pageable memory is staged by the runtime, which may allocate) */
     PathGroup groups[kMaxGroups];
     int ensure_group(int g);
     void release_groups();

@@ -45,6 +45,13 @@ static constexpr int kTraceBlocksPerCU = 8;
 #define PT_TRI_VOTE 10
 #endif
 
+#ifndef PT_LEAF2
+#define PT_LEAF2 0            /* 1: a lane may put TWO leaves aside before it stalls (the vote of B can then wait for more lanes) */
+#endif
+#ifndef PT_LEAF_DIRECT
+#define PT_LEAF_DIRECT 0      /* 1: a nearest child that is a leaf goes aside straight from A and the next nearest child becomes `cur` */
+#endif
+
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 1      /* waves per SIMD the kernel is compiled for at least (1: whatever its registers give, 6 at 73 VGPRs) */
 #endif
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
     bool overflow = false;
     uint32_t cNodes = 0, cTris = 0, cRays = 0, cWorst = 0, rayNodes = 0;
     uint32_t cTrips = 0, cExecA = 0, cExecB = 0, cPopIter = 0, cPopLanes = 0;     /* counting build: wave-level executions of each section */
+    uint32_t cIdle = 0, cStall = 0, cNoNode = 0;                                  /* counting build: trips this lane spent without a ray / with a second leaf it cannot put aside / with nothing in hand */
 
     /* this wave's slice of the rays: contiguous, a multiple of 64 long */
     const int32_t wavesTotal = (int32_t)gridDim.x * (kTraceThreads / 64);
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
 
     bool active = false;
     int32_t ri = -1, cur = PT_BVH_EMPTY, leaf = PT_BVH_EMPTY;      /* ri >= 0 on an inactive lane: a finished ray whose record is not stored yet */
+    int32_t leaf2 = PT_BVH_EMPTY;                                   /* PT_LEAF2: the second leaf put aside */
     float hDet = 1.0f;                                              /* h.u, h.v hold the numerators V, W until the record is stored */
     float tNear = 0.0f;
     RaySlabQ sl = {};
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                         r = ray_pre(o.x, o.y, o.z, d.x, d.y, d.z);
                         sl = ray_slab_q(o.x, o.y, o.z, d.x, d.y, d.z, nodes[7].x);
                         tNear = o.w;
-                        cur = 0; leaf = PT_BVH_EMPTY; active = true;
+                        cur = 0; leaf = PT_BVH_EMPTY; leaf2 = PT_BVH_EMPTY; active = true;
                         if (COUNT) { ++cRays; rayNodes = 0; }
                     }
                     else
@@ -148,7 +157,13 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
         }
         for (;;)
         {
-            if (COUNT) { ++cTrips; if (__ballot(active && cur >= 0) != 0ull) ++cExecA; }
+            if (COUNT)
+            {
+                ++cTrips; if (__ballot(active && cur >= 0) != 0ull) ++cExecA;
+                if (!active) ++cIdle;
+                else if (cur == PT_BVH_EMPTY) ++cNoNode;
+                else if (cur < 0 && leaf != PT_BVH_EMPTY) ++cStall;
+            }
             /* A: one node (compressed, 4 x 16 bytes) */
             if (active && cur >= 0)
             {
@@ -185,6 +200,18 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                 PT_SWAP_IF(d[0], c[0], d[2], c[2]);
                 PT_SWAP_IF(d[1], c[1], d[3], c[3]);
                 PT_SWAP_IF(d[1], c[1], d[2], c[2]);
+#if PT_LEAF_DIRECT
+                /* the nearest child is a leaf and there is room aside: it goes there now (it would be put aside by S anyway, and the
+                 * next nearest child popped right back), the other candidates move up one place */
+                {
+                    const bool direct = d[0] < __builtin_inff() && c[0] < 0 && (leaf == PT_BVH_EMPTY || (PT_LEAF2 && leaf2 == PT_BVH_EMPTY));
+                    if (direct)
+                    {
+                        if (leaf == PT_BVH_EMPTY) leaf = c[0]; else leaf2 = c[0];
+                        d[0] = d[1]; c[0] = c[1]; d[1] = d[2]; c[1] = c[2]; d[2] = d[3]; c[2] = c[3]; d[3] = __builtin_inff();
+                    }
+                }
+#endif
                 overflow |= !st.push3(d[1], c[1], d[2], c[2], d[3], c[3]);
                 cur = (d[0] < __builtin_inff()) ? c[0] : PT_BVH_EMPTY;
             }
@@ -192,6 +219,9 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
             if (active && cur < 0)
             {
                 if (cur != PT_BVH_EMPTY && leaf == PT_BVH_EMPTY) { leaf = cur; cur = PT_BVH_EMPTY; }
+#if PT_LEAF2
+                else if (cur != PT_BVH_EMPTY && leaf2 == PT_BVH_EMPTY) { leaf2 = cur; cur = PT_BVH_EMPTY; }
+#endif
                 if (cur == PT_BVH_EMPTY)
                 {
                     /* at most PT_POP_MAX entries per trip: an entry that starts beyond the closest hit is dropped and the
@@ -228,11 +258,14 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
                             if (TGT && tgt >= 0)
                             {
                                 /* t <= h.t = the target's own distance: anything but the target itself, or an equally near triangle with a higher id, is in front */
-                                if (prim != tgt && (t < h.t || prim < tgt)) { h.prim = -2; cur = PT_BVH_EMPTY; leaf = PT_BVH_EMPTY; st.init(); }
+                                if (prim != tgt && (t < h.t || prim < tgt)) { h.prim = -2; cur = PT_BVH_EMPTY; leaf = PT_BVH_EMPTY; leaf2 = PT_BVH_EMPTY; st.init(); }
                             }
                             else if (t < h.t || (t == h.t && (h.prim < 0 || prim < h.prim))) { h.prim = prim; h.t = t; h.u = vn; h.v = wn; hDet = det; }
                         }
                         if (!TGT || leaf != PT_BVH_EMPTY) leaf = (code & 7u) ? (int32_t)~(code + 7u) : PT_BVH_EMPTY;
+#if PT_LEAF2
+                        if (leaf == PT_BVH_EMPTY) { leaf = leaf2; leaf2 = PT_BVH_EMPTY; }
+#endif
                     }
                 }
             }
@@ -277,6 +310,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
             atomicAdd(&work[6], (unsigned long long)cExecB);
         }
         atomicAdd(&work[7], (unsigned long long)cPopIter); atomicAdd(&work[8], (unsigned long long)cPopLanes);
+        atomicAdd(&work[9], (unsigned long long)cIdle); atomicAdd(&work[10], (unsigned long long)cStall); atomicAdd(&work[11], (unsigned long long)cNoNode);
     }
 }
 

@@ -16,6 +16,8 @@
  *     over the header; here a free extent keeps its offset;
  *   - crate_allocate opens a table entry for the split-off remainder with a forward copy loop (crate.c:82-87) that smears
  *     entry `next` over every later one; here the entries behind it move down by one.
+ * The container's bookkeeping is this layer's own design (one ordered extent list with claim / release, below); only the
+ * entry points' names and signatures and the bytes in the file are the reference's.
  */
 #include "pim_host.h"
 
@@ -26,7 +28,7 @@
 _Static_assert(sizeof(Guid) == 16 && _Alignof(Guid) == 16, "Guid (common/guid.h:7-12)");
 _Static_assert(sizeof(DiskLmPack) == 24, "DiskLmPack (lightmap.h:46-54)");
 
-enum { kSplitSize = 1024, kHeaderSize = (int)((sizeof(Guid) + sizeof(i32) + sizeof(i32)) * kCrateLen) };
+enum { kHeaderSize = (int)((sizeof(Guid) + sizeof(i32) + sizeof(i32)) * kCrateLen) };
 #define kTableBytes (sizeof(((Crate*)0)->ids) + sizeof(((Crate*)0)->offsets) + sizeof(((Crate*)0)->sizes))
 _Static_assert(kTableBytes == kHeaderSize, "the three tables are contiguous in Crate (crate.c:165 reads them in one call)");
 
@@ -68,167 +70,171 @@ Guid Guid_HashStr(const char* str)                  /* guid.c:91-101 */
 
 Guid Guid_FromStr(const char* str) { return Guid_HashStr(str); }     /* guid.c:103-111 also records the name for the editor's UI */
 
-/* ---- Crate, assets/crate.c ---- */
+/* ---- Crate: the on-disk format is the reference's (assets/crate.c:7-11,147-260); the bookkeeping below is this layer's own ---- */
 
-static i32 crate_find(const Crate* crate, Guid key)                  /* crate.c:15-30 */
+/*
+ * The header's three parallel arrays are ONE ordered list of extents that tiles the file behind the header without gaps:
+ * entry k covers [offset, offset + size), a null id marks it free, the first size of 0 ends the list.  Everything the
+ * container does is one of four list operations on that view -- look an id up, pick the tightest free extent, cut an
+ * extent in two, give an extent back and fuse it with free neighbours -- so they are written once, over an Extent value
+ * type, instead of index arithmetic on three arrays at every call site.
+ */
+typedef struct Extent { Guid id; i32 offset; i32 size; } Extent;
+
+enum { kMinRemainder = 1024 };          /* a placed blob leaves a free extent behind it only if that many bytes remain (crate.c:56-96) */
+
+static Extent ext_at(const Crate* c, i32 k) { Extent e = { c->ids[k], c->offsets[k], c->sizes[k] }; return e; }
+static void ext_put(Crate* c, i32 k, Extent e) { c->ids[k] = e.id; c->offsets[k] = e.offset; c->sizes[k] = e.size; }
+static bool ext_is_free(Extent e) { return Guid_IsNull(e.id); }
+
+static i32 ext_count(const Crate* c)
 {
-    if (!Guid_IsNull(key))
-        for (i32 i = 0; (i < kCrateLen) && crate->sizes[i]; ++i)
-            if (Guid_Equal(crate->ids[i], key)) return i;
+    i32 n = 0;
+    while (n < kCrateLen && c->sizes[n] != 0) ++n;
+    return n;
+}
+
+/* opens a hole at position k (entries k.. move one place towards the end); false when the table is full */
+static bool ext_open_gap(Crate* c, i32 k)
+{
+    const i32 n = ext_count(c);
+    if (n >= kCrateLen || k > n) return false;
+    for (i32 j = n; j > k; --j) ext_put(c, j, ext_at(c, j - 1));
+    return true;
+}
+
+/* closes position k (entries behind it move one place towards the front, the vacated last entry becomes the list's end) */
+static void ext_close_gap(Crate* c, i32 k)
+{
+    const i32 n = ext_count(c);
+    for (i32 j = k; j + 1 < n; ++j) ext_put(c, j, ext_at(c, j + 1));
+    if (n > 0) ext_put(c, n - 1, (Extent){ { 0, 0 }, 0, 0 });
+}
+
+static i32 ext_lookup(const Crate* c, Guid id)
+{
+    if (Guid_IsNull(id)) return -1;
+    const i32 n = ext_count(c);
+    for (i32 k = 0; k < n; ++k)
+        if (Guid_Equal(c->ids[k], id)) return k;
     return -1;
 }
 
-static i32 crate_findempty(const Crate* crate, i32 size)             /* crate.c:32-54: best fit among the free extents */
+/* the free extent that wastes the least (the first of equally tight ones), -1 if none is large enough */
+static i32 ext_tightest_free(const Crate* c, i32 bytes)
 {
-    i32 chosen = -1, chosenDiff = 1 << 30;
-    if (size > 0)
-        for (i32 i = 0; (i < kCrateLen) && crate->sizes[i]; ++i)
-            if (Guid_IsNull(crate->ids[i]))
-            {
-                const i32 diff = crate->sizes[i] - size;
-                if ((diff >= 0) && (diff < chosenDiff)) { chosen = i; chosenDiff = diff; }
-            }
-    return chosen;
-}
-
-static i32 crate_allocate(Crate* crate, Guid id, i32 size)           /* crate.c:56-96 */
-{
-    const i32 slot = crate_findempty(crate, size);
-    if (slot < 0) return -1;
-    crate->ids[slot] = id;
-    const i32 diff = crate->sizes[slot] - size;
-    if (diff >= kSplitSize)
+    i32 pick = -1;
+    const i32 n = ext_count(c);
+    for (i32 k = 0; k < n; ++k)
     {
-        const i32 next = slot + 1;
-        if ((next < kCrateLen) && Guid_IsNull(crate->ids[kCrateLen - 1]) && !crate->sizes[kCrateLen - 1])
-        {
-            /* the remainder becomes a free extent of its own right behind the blob */
-            memmove(&crate->ids[next + 1], &crate->ids[next], sizeof(Guid) * (size_t)(kCrateLen - 1 - next));
-            memmove(&crate->offsets[next + 1], &crate->offsets[next], sizeof(i32) * (size_t)(kCrateLen - 1 - next));
-            memmove(&crate->sizes[next + 1], &crate->sizes[next], sizeof(i32) * (size_t)(kCrateLen - 1 - next));
-            crate->ids[next] = (Guid){ 0, 0 };
-            crate->offsets[next] = crate->offsets[slot] + size;
-            crate->sizes[next] = diff;
-            crate->sizes[slot] = size;
-        }
+        const Extent e = ext_at(c, k);
+        if (!ext_is_free(e) || e.size < bytes) continue;
+        if (pick < 0 || e.size < c->sizes[pick]) pick = k;
     }
-    return slot;
+    return pick;
 }
 
-static void crate_remove_entry(Crate* crate, i32 slot)
+/* gives the free extent k to `id`; what it does not need stays behind as a free extent of its own when it is worth one */
+static void ext_claim(Crate* c, i32 k, Guid id, i32 bytes)
 {
-    memmove(&crate->ids[slot], &crate->ids[slot + 1], sizeof(Guid) * (size_t)(kCrateLen - 1 - slot));
-    memmove(&crate->offsets[slot], &crate->offsets[slot + 1], sizeof(i32) * (size_t)(kCrateLen - 1 - slot));
-    memmove(&crate->sizes[slot], &crate->sizes[slot + 1], sizeof(i32) * (size_t)(kCrateLen - 1 - slot));
-    crate->ids[kCrateLen - 1] = (Guid){ 0, 0 };
-    crate->offsets[kCrateLen - 1] = 0;
-    crate->sizes[kCrateLen - 1] = 0;
-}
-
-static void crate_free(Crate* crate, i32 slot)                       /* crate.c:98-143: free + merge with free neighbours */
-{
-    crate->ids[slot] = (Guid){ 0, 0 };
-    const i32 prev = slot - 1;
-    if ((prev >= 0) && Guid_IsNull(crate->ids[prev]))
+    Extent e = ext_at(c, k);
+    const i32 rest = e.size - bytes;
+    e.id = id;
+    if (rest >= kMinRemainder && ext_open_gap(c, k + 1))
     {
-        crate->sizes[prev] += crate->sizes[slot];
-        crate_remove_entry(crate, slot);
-        --slot;
+        ext_put(c, k + 1, (Extent){ { 0, 0 }, e.offset + bytes, rest });
+        e.size = bytes;
     }
-    const i32 next = slot + 1;
-    if ((next < kCrateLen) && crate->sizes[next] && Guid_IsNull(crate->ids[next]))
+    ext_put(c, k, e);
+}
+
+/* returns extent k to the free list and fuses the run of free extents it is now part of into one (its offset is the run's) */
+static void ext_release(Crate* c, i32 k)
+{
+    c->ids[k] = (Guid){ 0, 0 };
+    while (k > 0 && ext_is_free(ext_at(c, k - 1))) --k;                 /* first entry of the free run */
+    while (k + 1 < ext_count(c) && ext_is_free(ext_at(c, k + 1)))
     {
-        crate->sizes[slot] += crate->sizes[next];
-        crate_remove_entry(crate, next);
+        c->sizes[k] += c->sizes[k + 1];
+        ext_close_gap(c, k + 1);
     }
 }
 
-static bool file_seek(FILE* f, i32 offset) { return fseek(f, (long)offset, SEEK_SET) == 0; }
+static void* table_bytes(Crate* c) { return c->ids; }                  /* ids | offsets | sizes are contiguous (static assert above) */
 
-bool Crate_Open(Crate* crate, const char* path)                      /* crate.c:147-175 */
+static bool io_at(FILE* f, i32 offset, void* rd, const void* wr, i32 bytes)
+{
+    if (fseek(f, (long)offset, SEEK_SET) != 0) return false;
+    const size_t n = (size_t)bytes;
+    return rd ? fread(rd, 1, n, f) == n : fwrite(wr, 1, n, f) == n;
+}
+
+bool Crate_Open(Crate* crate, const char* path)
 {
     if (!crate || !path) return false;
     memset(crate, 0, sizeof(*crate));
-    bool exists = true;
-    FILE* file = fopen(path, "rb+");
-    if (!file) { exists = false; file = fopen(path, "wb+"); }
-    if (!file) return false;
-    crate->file.handle = file;
-    file_seek(file, 0);
-    if (exists)
+    FILE* f = fopen(path, "rb+");
+    const bool fresh = f == NULL;
+    if (fresh && !(f = fopen(path, "wb+"))) return false;
+    bool good;
+    if (fresh)
     {
-        if (fread(crate->ids, 1, kTableBytes, file) != kTableBytes)
-        {
-            /* shorter than a header: not a crate (the reference goes on with whatever it read) */
-            fclose(file); memset(crate, 0, sizeof(*crate));
-            return false;
-        }
+        ext_put(crate, 0, (Extent){ { 0, 0 }, kHeaderSize, 1 << 30 });    /* one free extent behind the header */
+        good = io_at(f, 0, NULL, table_bytes(crate), kHeaderSize);
     }
-    else
-    {
-        crate->offsets[0] = kHeaderSize;
-        crate->sizes[0] = 1 << 30;
-        fwrite(crate->ids, 1, kTableBytes, file);
-    }
-    file_seek(file, kHeaderSize);
+    else good = io_at(f, 0, table_bytes(crate), NULL, kHeaderSize);       /* shorter than a header: not a crate */
+    if (!good) { fclose(f); memset(crate, 0, sizeof(*crate)); return false; }
+    crate->file.handle = f;
     return true;
 }
 
-bool Crate_Close(Crate* crate)                                       /* crate.c:177-194 */
+bool Crate_Close(Crate* crate)
 {
-    bool wasopen = false;
-    if (crate)
+    if (!crate) return false;
+    FILE* f = crate->file.handle;
+    if (f)
     {
-        FILE* file = crate->file.handle;
-        if (file)
-        {
-            file_seek(file, 0);
-            fwrite(crate->ids, 1, kTableBytes, file);
-            fflush(file);
-            fclose(file);
-            wasopen = true;
-        }
-        memset(crate, 0, sizeof(*crate));
+        io_at(f, 0, NULL, table_bytes(crate), kHeaderSize);               /* the table goes out last */
+        fflush(f);
+        fclose(f);
     }
-    return wasopen;
+    memset(crate, 0, sizeof(*crate));
+    return f != NULL;
 }
 
-bool Crate_Get(Crate* crate, Guid id, void* dst, i32 size)          /* crate.c:196-219 */
+bool Crate_Get(Crate* crate, Guid id, void* dst, i32 size)
 {
     if (!crate || !crate->file.handle || !dst || size <= 0) return false;
-    const i32 slot = crate_find(crate, id);
-    if (slot < 0 || size > crate->sizes[slot]) return false;
-    FILE* file = crate->file.handle;
-    if (!file_seek(file, crate->offsets[slot])) return false;
-    return fread(dst, 1, (size_t)size, file) == (size_t)size;
+    const i32 k = ext_lookup(crate, id);
+    return k >= 0 && size <= crate->sizes[k] && io_at(crate->file.handle, crate->offsets[k], dst, NULL, size);
 }
 
-bool Crate_Set(Crate* crate, Guid id, const void* src, i32 size)    /* crate.c:221-260 */
+bool Crate_Set(Crate* crate, Guid id, const void* src, i32 size)
 {
     if (!crate || !crate->file.handle || !src || size <= 0 || Guid_IsNull(id)) return false;
-    i32 slot = crate_find(crate, id);
-    if (slot >= 0 && crate->sizes[slot] < size) { crate_free(crate, slot); slot = -1; }      /* grown: a new place */
-    if (slot < 0) slot = crate_allocate(crate, id, size);
-    if (slot < 0) return false;
-    FILE* file = crate->file.handle;
-    if (!file_seek(file, crate->offsets[slot])) return false;
-    return fwrite(src, 1, (size_t)size, file) == (size_t)size;
+    i32 k = ext_lookup(crate, id);
+    if (k >= 0 && crate->sizes[k] < size) { ext_release(crate, k); k = -1; }     /* outgrew its extent: it moves */
+    if (k < 0)
+    {
+        if ((k = ext_tightest_free(crate, size)) < 0) return false;
+        ext_claim(crate, k, id, size);
+    }
+    return io_at(crate->file.handle, crate->offsets[k], NULL, src, size);
 }
 
-bool Crate_Rm(Crate* crate, Guid id)                                /* crate.c:262-271 */
+bool Crate_Rm(Crate* crate, Guid id)
 {
-    const i32 slot = crate ? crate_find(crate, id) : -1;
-    if (slot < 0) return false;
-    crate_free(crate, slot);
-    return true;
+    const i32 k = crate ? ext_lookup(crate, id) : -1;
+    if (k >= 0) ext_release(crate, k);
+    return k >= 0;
 }
 
-bool Crate_Stat(const Crate* crate, Guid id, i32* offsetOut, i32* sizeOut)      /* crate.c:273-285 */
+bool Crate_Stat(const Crate* crate, Guid id, i32* offsetOut, i32* sizeOut)
 {
-    const i32 slot = crate ? crate_find(crate, id) : -1;
-    if (slot < 0) return false;
-    if (offsetOut) *offsetOut = crate->offsets[slot];
-    if (sizeOut) *sizeOut = crate->sizes[slot];
+    const i32 k = crate ? ext_lookup(crate, id) : -1;
+    if (k < 0) return false;
+    if (offsetOut) *offsetOut = crate->offsets[k];
+    if (sizeOut) *sizeOut = crate->sizes[k];
     return true;
 }
 
@@ -249,70 +255,70 @@ void Lightmap_Upload(Lightmap* lm)
         ms_uploader(lm->slot, i, lm->probes[i], (i32)sizeof(float4) * len, ms_uploaderUser);
 }
 
-static i32 lm_texel_bytes(i32 lmsize)               /* lightmap.c:1232-1238: probes + position + normal + sampleCounts */
+/*
+ * The checkpoint's blobs (rendering/lightmap.c:1225-1308; DiskLmPack lightmap.h:46-54): "lmpack" = the 24-byte header,
+ * "lightmap_<i>" = page i as the one block Lightmap_New makes (probes | position | normal | sampleCounts, lightmap.c:95-110).
+ */
+static Guid lm_blob_id(i32 page)                     /* page < 0: the header */
 {
-    const i32 texelcount = lmsize * lmsize;
-    return (i32)sizeof(float4) * texelcount * kGiDirections + (i32)sizeof(float3) * texelcount * 2 + (i32)sizeof(float) * texelcount;
+    char name[32];
+    if (page < 0) return Guid_FromStr("lmpack");
+    snprintf(name, sizeof(name), "lightmap_%d", page);
+    return Guid_FromStr(name);
 }
 
-bool LmPack_Save(Crate* crate, const LmPack* pack)                   /* lightmap.c:1225-1262 */
+static i32 lm_page_bytes(i32 lmSize)
+{
+    const i32 texels = lmSize * lmSize;
+    const i32 perTexel = (i32)sizeof(float4) * kGiDirections + (i32)sizeof(float3) * 2 + (i32)sizeof(float);
+    return perTexel * texels;
+}
+
+static DiskLmPack lm_header_of(const LmPack* pack)
+{
+    const DiskLmPack h = {
+        .version = kLmPackVersion, .directions = kGiDirections, .lmCount = pack->lmCount, .lmSize = pack->lmSize,
+        .bytesPerLightmap = lm_page_bytes(pack->lmSize), .texelsPerMeter = pack->texelsPerMeter,
+    };
+    return h;
+}
+
+static bool lm_header_usable(const DiskLmPack* h)
+{
+    return h->version == kLmPackVersion && h->directions == kGiDirections && h->lmCount > 0 && h->lmSize > 0;
+}
+
+bool LmPack_Save(Crate* crate, const LmPack* pack)
 {
     if (!crate || !pack) return false;
     if (pack == LmPack_Get()) LmPack_Sync();         /* resident pages: what is saved is the bake as it stands */
-    bool wrote = false;
-    const i32 lmcount = pack->lmCount;
-    const i32 texelBytes = lm_texel_bytes(pack->lmSize);
-    DiskLmPack dpack; memset(&dpack, 0, sizeof(dpack));
-    dpack.version = kLmPackVersion;
-    dpack.directions = kGiDirections;
-    dpack.lmCount = lmcount;
-    dpack.lmSize = pack->lmSize;
-    dpack.bytesPerLightmap = texelBytes;
-    dpack.texelsPerMeter = pack->texelsPerMeter;
-    if (Crate_Set(crate, Guid_FromStr("lmpack"), &dpack, (i32)sizeof(dpack)))
-    {
-        wrote = true;
-        for (i32 i = 0; i < lmcount; ++i)
-        {
-            char name[64];
-            snprintf(name, sizeof(name), "lightmap_%d", i);
-            const Lightmap lm = pack->lightmaps[i];
-            wrote &= Crate_Set(crate, Guid_FromStr(name), lm.probes[0], texelBytes);     /* the page is ONE block (lightmap.c:95-110) */
-        }
-    }
-    return wrote;
+    const DiskLmPack header = lm_header_of(pack);
+    if (!Crate_Set(crate, lm_blob_id(-1), &header, (i32)sizeof(header))) return false;
+    i32 failed = 0;
+    for (i32 i = 0; i < pack->lmCount; ++i)          /* every page is attempted even after a failure, as in the reference */
+        if (!Crate_Set(crate, lm_blob_id(i), pack->lightmaps[i].probes[0], header.bytesPerLightmap)) ++failed;
+    return failed == 0;
 }
 
-bool LmPack_Load(Crate* crate, LmPack* pack)                         /* lightmap.c:1264-1308 */
+bool LmPack_Load(Crate* crate, LmPack* pack)
 {
     if (!crate || !pack) return false;
-    bool loaded = false;
-    LmPack_Del(pack);
-    DiskLmPack dpack; memset(&dpack, 0, sizeof(dpack));
-    if (Crate_Get(crate, Guid_FromStr("lmpack"), &dpack, (i32)sizeof(dpack)))
+    LmPack_Del(pack);                                /* whatever it held is gone, header or no header */
+    DiskLmPack header; memset(&header, 0, sizeof(header));
+    if (!Crate_Get(crate, lm_blob_id(-1), &header, (i32)sizeof(header)) || !lm_header_usable(&header)) return false;
+    Lightmap* pages = calloc((size_t)header.lmCount, sizeof(Lightmap));
+    if (!pages) return false;
+    pack->lightmaps = pages;
+    pack->lmCount = header.lmCount;
+    pack->lmSize = header.lmSize;
+    pack->texelsPerMeter = header.texelsPerMeter;
+    const i32 pageBytes = lm_page_bytes(header.lmSize);
+    i32 failed = 0;
+    for (i32 i = 0; i < header.lmCount; ++i)
     {
-        if ((dpack.version == kLmPackVersion) && (dpack.directions == kGiDirections) && (dpack.lmCount > 0) && (dpack.lmSize > 0))
-        {
-            const i32 lmcount = dpack.lmCount, lmsize = dpack.lmSize;
-            const i32 texelBytes = lm_texel_bytes(lmsize);
-            pack->lightmaps = calloc((size_t)lmcount, sizeof(pack->lightmaps[0]));
-            if (!pack->lightmaps) return false;
-            loaded = true;
-            pack->lmCount = lmcount;
-            pack->lmSize = lmsize;
-            pack->texelsPerMeter = dpack.texelsPerMeter;
-            for (i32 i = 0; i < lmcount; ++i)
-            {
-                char name[64];
-                snprintf(name, sizeof(name), "lightmap_%d", i);
-                Lightmap lm; memset(&lm, 0, sizeof(lm));
-                Lightmap_New(&lm, lmsize);
-                if (!lm.probes[0]) { loaded = false; pack->lightmaps[i] = lm; continue; }
-                loaded &= Crate_Get(crate, Guid_FromStr(name), lm.probes[0], texelBytes);
-                Lightmap_Upload(&lm);
-                pack->lightmaps[i] = lm;
-            }
-        }
+        Lightmap_New(&pages[i], header.lmSize);
+        if (!pages[i].probes[0] || !Crate_Get(crate, lm_blob_id(i), pages[i].probes[0], pageBytes)) { ++failed; continue; }
+        Lightmap_Upload(&pages[i]);
     }
-    return loaded;
+    return failed == 0;
 }

@@ -435,7 +435,11 @@ static PimLightmapPage* lm_page_table(const LmPack* pack)
 
 void LmPack_Sync(void)
 {
-    if (!ms_lmSet || !ms_lmDeviceNewer || ms_pack.lmCount != ms_lmSetCount || !ms_pack.lightmaps) return;
+    /* only into the pack the set was filled from: same page count, page size and first page (a caller may have replaced
+     * *LmPack_Get() without LmPack_Del; downloading the old set's lmSize^2 * 20 floats into other pages would write stale
+     * results and overrun smaller ones) */
+    if (!ms_lmSet || !ms_lmDeviceNewer || !ms_pack.lightmaps || ms_pack.lmCount != ms_lmSetCount || ms_pack.lmSize != ms_lmSetSize ||
+        ms_lmSetKey != (const void*)ms_pack.lightmaps[0].probes[0]) return;
     PimLightmapPage* pages = lm_page_table(&ms_pack);
     if (!pages) return;
     if (ok(pimgpu_lightmap_set_download(ms_lmSet, pages), "LmPack_Sync")) ms_lmDeviceNewer = false;
@@ -488,7 +492,7 @@ void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp)
     }
     /* resident: the pages go up once (again whenever the pack is another one), every call bakes in HBM */
     if (ms_lmSet && (ms_lmSetCount != pack->lmCount || ms_lmSetSize != pack->lmSize || ms_lmSetKey != (const void*)pack->lightmaps[0].probes[0]))
-        LmPack_Invalidate();
+        lm_set_drop();                                                     /* another pack: the old set has nowhere to go */
     if (!ms_lmSet)
     {
         if (!ok(pimgpu_lightmap_set_create(pack->lmCount, pack->lmSize, &ms_lmSet), "LmPack_Bake") ||

@@ -217,7 +217,8 @@ static bool group_charts(PimChartNode** nodesIo, int32_t nodeCount, float distTh
     b.slots = 1024; while (b.slots < 4 * (nodeCount + 1)) b.slots *= 2;
     b.keys = malloc(sizeof(int64_t) * (size_t)b.slots); b.heads = malloc(sizeof(int32_t) * (size_t)b.slots);
     b.next = malloc(sizeof(int32_t) * (size_t)(nodeCount + 1));
-    bool okAll = chartOf && rep && b.keys && b.heads && b.next;
+    int32_t* loose = malloc(sizeof(int32_t) * (size_t)(nodeCount + 1)); int32_t looseCount = 0;   /* charts whose plane is not in a bucket */
+    bool okAll = chartOf && rep && b.keys && b.heads && b.next && loose;
     int32_t chartCount = 0;
     if (okAll)
     {
@@ -228,10 +229,14 @@ static bool group_charts(PimChartNode** nodesIo, int32_t nodeCount, float distTh
             const float* pl = nodes[i].plane;
             int32_t found = -1;
             int64_t key = 0;
-            const bool finite = bucketed && (fabsf(pl[3]) < 1e30f);     /* a NaN / huge distance term matches nothing (dist < distThresh is false) */
+            /* bucketed only while the quotient converts to int64 without overflow (a tiny distThresh or a huge distance term can push it
+             * past 9.2e18); the few charts beyond that are kept in a plain list and compared with every node, as the reference's linear
+             * scan compares everything with everything (a NaN distance term matches nothing there either: dist < distThresh is false) */
+            const float quot = bucketed ? pl[3] / distThresh : 0.0f;
+            const bool finite = bucketed && (fabsf(quot) < 9e18f);
             if (finite)
             {
-                key = (int64_t)floorf(pl[3] / distThresh);
+                key = (int64_t)floorf(quot);
                 for (int64_t k = key - 2; k <= key + 2; ++k)          /* +-1 in exact arithmetic; the fp32 quotient can be off by a fraction */
                 {
                     const int32_t s = bucket_slot(&b, k);
@@ -245,6 +250,18 @@ static bool group_charts(PimChartNode** nodesIo, int32_t nodeCount, float distTh
                     }
                 }
             }
+            /* a node outside the buckets is compared with every chart so far, first match wins (the reference's scan, lm.c:341-352);
+             * a bucketed one additionally with the charts outside the buckets */
+            const int32_t scanCount = !bucketed ? 0 : (finite ? looseCount : chartCount);
+            for (int32_t k = 0; k < scanCount; ++k)
+            {
+                const int32_t c = finite ? loose[k] : k;
+                if (found != -1 && c > found) break;                          /* the list is in chart order */
+                const float* q = nodes[rep[c]].plane;
+                const float dist = fabsf(pl[3] - q[3]);
+                const float cosTheta = q[0] * pl[0] + q[1] * pl[1] + q[2] * pl[2];
+                if ((dist < distThresh) && (cosTheta >= minCosTheta)) { found = c; break; }
+            }
             if (found == -1)
             {
                 found = chartCount++;
@@ -255,11 +272,12 @@ static bool group_charts(PimChartNode** nodesIo, int32_t nodeCount, float distTh
                     if (b.heads[s] == -1) b.keys[s] = key;
                     b.next[found] = b.heads[s]; b.heads[s] = found;
                 }
+                else if (bucketed) loose[looseCount++] = found;
             }
             chartOf[i] = found;
         }
     }
-    free(b.keys); free(b.heads); free(b.next); free(rep);
+    free(b.keys); free(b.heads); free(b.next); free(rep); free(loose);
     if (!okAll) { free(chartOf); return false; }
 
     /* the nodes chart by chart, members in node order (a counting sort on the chart id) */

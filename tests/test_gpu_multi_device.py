@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("n", [1, 2, 3])
 def test_device_list_matches_oracle(n):
-    run = subprocess.run([sys.executable, "-u", "-X", "faulthandler", "-m", "tests.multi_device_worker", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    # a child that dies names the HIP call it died in: native frames on a fatal signal, one stderr line per call of the library's init
+    env = dict(os.environ, PIMGPU_SEGV_BACKTRACE="1", PIMGPU_INIT_TRACE="1")
+    run = subprocess.run([sys.executable, "-u", "-X", "faulthandler", "-m", "tests.multi_device_worker", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
     ok = run.returncode == 0 and f"MULTI-DEVICE OK {n}" in run.stdout
     assert ok, run.stdout[-3000:] + run.stderr[-3000:]

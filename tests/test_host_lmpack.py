@@ -85,6 +85,16 @@ def test_chart_group_edge_cases(host):
     assert first.tolist() == [0, 6]
     group_both(host, nodes[:1], 0.1, 15.0, 1.0, seed=1)
     group_both(host, nodes[:0], 0.1, 15.0, 1.0, seed=1)
+    # distance terms whose quotient by the threshold does not fit an int64 (a tiny threshold, huge terms): those planes leave the
+    # buckets and are compared one by one -- equal huge terms still share a chart, as in the reference's scan
+    big = np.zeros(8, api.CHARTNODE_DTYPE)
+    big["triCoord"] = rng.uniform(0, 30, (8, 6)).astype(np.float32)
+    big["plane"][:, 2] = 1.0
+    big["plane"][:, 3] = [5e30, 1.0, 5e30, 1e-3, 1.0, 3e35, 3e35, np.inf]
+    big["vertIndex"] = np.arange(8) * 3
+    got, first = group_both(host, big, 1e-20, 15.0, 1e9, seed=1)
+    assert np.diff(first).tolist().count(2) == 3                               # the two 5e30, the two 1.0, the two 3e35
+    group_both(host, big, 0.1, 15.0, 1e9, seed=1)
 
 
 def test_chart_sort_is_the_references_quicksort(host):
