@@ -40,13 +40,26 @@ sys.path.insert(0, ROOT)
 from pim_amd import api, scenes  # noqa: E402
 from pim_amd import dist as pdist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0             # HBM3E, spec
+L2_PEAK_GBS = 34500.0             # aggregate L2 bandwidth (8 XCDs x 4 MiB), "L2 (per XCD)"
+IC_GATHER_PEAK_GBS = 8600.0       # rows gathered at random from a 38 MB table that lives in the Infinity Cache, "Indexed rows"
+# VALU issue: the guide's fp32 vector peak (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz) is one wave64
+# instruction per SIMD every 2 cycles: 1228.8 G wave-instructions/s.  What this pool's chips sustain with every SIMD full of
+# independent instructions and no memory traffic (scripts/micro/valu_peak.hip -> profiles/r03_valu_issue_peak.txt; the counter
+# SQ_INSTS_VALU counts exactly one per wave64 instruction, profiles/r03_valu_issue_peak_pmc_calibration.txt): 797 G/s on
+# v_fma_f32 alone, 490-520 G/s on v_max3_f32 / v_cvt_f32_ubyte0 -- reported beside the spec ceiling as `attainable`.
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+VALU_ATTAINABLE_GINST = 796.6
 
 WORKLOADS = {
     "synth1m_4k": dict(scene="synth1m", width=3840, height=2160, bounces=8),
     "synth1m_1080p": dict(scene="synth1m", width=1920, height=1080, bounces=8),
     "cornell_1080p": dict(scene="cornell", width=1920, height=1080, bounces=8),
     "cornell_360p": dict(scene="cornell", width=640, height=360, bounces=4),
+    # config #5 on one GPU: the 20M-triangle diffuse scene, FULL BVH rebuild + 1 spp per step (the HBM-bound case: 2.9 GB of
+    # vertices + 1.7 GB of tree do not fit the 256 MiB Infinity Cache)
+    "synth20m_1080p": dict(scene="synth20m", width=1920, height=1080, bounces=8, rebuild=True),
 }
 DEFAULT_WORKLOAD = "synth1m_4k"
 
@@ -65,20 +78,24 @@ def build_scene(kind):
         elif kind == "synth1m":
             sc = scenes.synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, emissive_attempts=64)
             cam = scenes.synthetic_camera(100.0)
+        elif kind == "synth20m":
+            sc = scenes.synthetic_scene(target_tris=20_000_000, seed=1234, extent=100.0, emissive_attempts=4, diffuse_only=True)
+            cam = scenes.synthetic_camera(100.0)
         else:
             raise ValueError(kind)
         _SCENES[kind] = (sc, cam, api.Scene(sc.desc))
     return _SCENES[kind]
 
 
-def load_traffic(workload):
-    """HBM-side bytes per k_trace launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 runs
-    of this same command: scripts/profile_bench.sh -> profiles/traffic.json).  Counters cannot be read inside this
-    process: the figure is the COMMITTED measurement of this workload (tagged as such), or None."""
+def load_profile(workload):
+    """per-kernel-class figures of this workload from the committed rocprofv3 --pmc passes (scripts/profile_bench.sh ->
+    scripts/pmc_per_unit.py -> profiles/traffic.json): VALU wave-instructions, HBM-side bytes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE), vector-L1 accesses per unit of work, lanes per VALU instruction, L2 hit rate.  Counters cannot be read inside
+    this process: these are the COMMITTED measurements of the same command (tagged with their source), or nothing."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
-        return None
-    return json.load(open(tpath)).get(workload)
+        return {}
+    return (json.load(open(tpath)).get(workload) or {}).get("kernels") or {}
 
 
 def cpu_baseline(sc, cam, wl, threads):
@@ -119,10 +136,14 @@ class Run:
         self.trace = api.Trace(self.W, self.H)
         self.dof = scenes.default_dof()
         self.acc = {}
+        self.build_ms = 0.0
 
-    def step(self, i, sample_index=None):
-        p = scenes.trace_params(i, seed=1, max_bounces=self.wl["bounces"])
+    def step(self, i, sample_index=None, update_dists=1):
+        p = scenes.trace_params(i, seed=1, max_bounces=self.wl["bounces"], update_dists=update_dists)
         p.sampleIndex = sample_index if sample_index is not None else pdist.sample_indices(self.rank, self.world, i + 1)[i]
+        if self.wl.get("rebuild"):
+            self.scene.rebuild_bvh()                      # config 5: rtcCommitScene every frame (path_tracer.c:687)
+            self.build_ms = self.build_ms + self.scene.info().bvhBuildMs
         self.trace.trace(self.scene, self.cam, self.dof, p)
         return self.trace.stats()
 
@@ -154,51 +175,78 @@ class Run:
         tail = (max(na - nb, 0) / rt, max(ta - tb, 0) / rt, worst_all)
         return batched, tail
 
-    def rooflines(self, steps, dt_ms_per_step):
-        """one entry per kernel class with its share of the step.  `achieved` = ALGORITHMIC bytes / device time of the kernel's
-        launches (events attached to the dispatches, on the library's stream)."""
+    def rooflines(self, steps, dt_ms_per_step, plain=False):
+        """One entry per kernel class of the step.  Every entry carries THREE ceilings and names the one that binds:
+          valu  wave-instructions per second against the VALU issue peak (instructions per unit from the committed PMC passes of
+                this workload x the units of THIS run / the kernel's device time in THIS run, from events attached to the dispatches);
+          hbm   HBM-side bytes per second (FETCH_SIZE x2 + WRITE_SIZE per unit, same source, same scaling) against 8 TB/s;
+          cache the ALGORITHMIC bytes (64 B per node visit, 48 B per triangle test, the path state a stage streams)
+                against the L2's 34.5 TB/s -- most of them are cache hits, so against HBM they can exceed 1 and say nothing.
+        `bound` / `achieved` / `peak` / `unit` / `frac` are those of the ceiling with the largest fraction."""
         a = self.acc
-        (nodes, tris, worst), (tnodes, ttris, tworst) = self.work_per_ray(steps)
+        if plain:
+            (nodes, tris, worst), (tnodes, ttris, tworst) = (0.0, 0.0, 0), (0.0, 0.0, 0)
+        else:
+            (nodes, tris, worst), (tnodes, ttris, tworst) = self.work_per_ray(steps)
         b_ray = 48.0 + 64.0 * nodes + 48.0 * tris
         b_ray_tail = 48.0 + 64.0 * tnodes + 48.0 * ttris
         rays = a["extensionRays"] + a["shadowRays"] + a["otherRays"]
         batched = rays - a["tailRays"]
         launches = max(a["traceLaunches"], 1)
         device_ms = a["totalMs"] / steps
+        prof = load_profile(self.name)
         out = []
 
         def entry(kernel, ms_total, bytes_total, units, unit_name, bytes_per_unit, **extra):
-            ach = bytes_total / (ms_total * 1e-3) / 1e9 if ms_total > 0 else 0.0
-            e = {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                 "ms_per_step": ms_total / steps, "share_of_device_step": (ms_total / steps) / device_ms if device_ms > 0 else 0.0,
-                 "units_per_step": units / steps, "unit_name": unit_name, "algorithmic_bytes_per_unit": bytes_per_unit}
+            sec = ms_total * 1e-3
+            alg = bytes_total / sec / 1e9 if sec > 0 else 0.0
+            e = {"kernel": kernel, "ms_per_step": ms_total / steps, "share_of_device_step": (ms_total / steps) / device_ms if device_ms > 0 else 0.0,
+                 "units_per_step": units / steps, "unit_name": unit_name,
+                 "algorithmic_bytes_per_unit": bytes_per_unit if not plain else None,
+                 "algorithmic_GBps": alg if not plain else None,
+                 "algorithmic_frac_of_hbm_peak": alg / HBM_PEAK_GBS if not plain else None}
+            ceilings = {}
+            if not plain and alg > 0:
+                ceilings["cache"] = {"achieved": alg, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": alg / L2_PEAK_GBS,
+                                     "what": "algorithmic bytes against the L2's aggregate bandwidth (the data is served from L1 / L2 / the Infinity Cache)"}
+            pk = prof.get(kernel.split("<")[0])
+            if pk and sec > 0 and units > 0:
+                src = f"profiles/traffic.json [{pk.get('tag')}] = rocprofv3 --pmc passes of `{pk.get('command')}` ({pk.get('summary_file')}); per-unit figures of THAT run, scaled by the units and device time of THIS run"
+                if pk.get("valu_insts_per_unit"):
+                    g = units * pk["valu_insts_per_unit"] / sec / 1e9
+                    ceilings["valu"] = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
+                                        "wave_insts_per_unit": pk["valu_insts_per_unit"], "lanes_per_valu_inst": pk.get("lanes_per_valu_inst"),
+                                        "attainable_peak": VALU_ATTAINABLE_GINST, "frac_of_attainable": g / VALU_ATTAINABLE_GINST,
+                                        "what": "VALU issue: wave64 instructions per second against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (the fp32 vector peak); attainable = the v_fma_f32 rate measured on this pool", "source": src}
+                if pk.get("hbm_bytes_per_unit") is not None:
+                    g = units * pk["hbm_bytes_per_unit"] / sec / 1e9
+                    ceilings["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                       "bytes_per_unit": pk["hbm_bytes_per_unit"], "l2_hit_rate": pk.get("l2_hit_rate"),
+                                       "what": "HBM-side bytes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)", "source": src}
+                    e["traffic"] = units / steps * pk["hbm_bytes_per_unit"]          # HBM-side bytes per step of this kernel class
+                    if not plain and bytes_per_unit > 0:
+                        e["traffic_over_algorithmic"] = pk["hbm_bytes_per_unit"] / bytes_per_unit
+                if pk.get("l1_accesses_per_unit"):
+                    e["vector_l1_accesses_per_unit"] = pk["l1_accesses_per_unit"]
+            e.setdefault("traffic", None)
+            e["ceilings"] = ceilings
+            if ceilings:
+                name = max(ceilings, key=lambda k: ceilings[k]["frac"])
+                # the cache ceiling is a statement about algorithmic bytes; when a measured ceiling (valu / hbm) exists it names the bound
+                measured = {k: v for k, v in ceilings.items() if k != "cache"}
+                if measured:
+                    name = max(measured, key=lambda k: measured[k]["frac"])
+                c = ceilings[name]
+                e.update({"bound": name, "achieved": c["achieved"], "peak": c["peak"], "unit": c["unit"], "frac": c["frac"]})
+            else:
+                e.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
             e.update(extra)
             return e
 
-        trw = load_traffic(self.name) or {}
-        per_kernel = trw.get("kernels") or ({trw["kernel"]: trw} if trw.get("kernel") else {})
-
-        def attach_traffic(e, label, launch_ms):
-            """HBM-side bytes per launch of this kernel class from the committed PMC passes (not this run), and the DRAM-side rate they give"""
-            tr = per_kernel.get(label)
-            e["traffic"] = tr.get("bytes_per_launch") if tr else None
-            if tr and launch_ms > 0:
-                e["hbm_measured"] = {"bytes_per_launch": tr["bytes_per_launch"], "GBps": tr["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9,
-                                     "frac_of_peak": tr["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "l2_hit_rate": tr.get("l2_hit_rate"),
-                                     "source": f"profiles/traffic.json [{tr.get('tag')}]: rocprofv3 --pmc passes of `{tr.get('command')}`, NOT measured in this run"}
-                e["traffic_source"] = "profiles/traffic.json (committed PMC measurement of this workload, not this run)"
-
         avg_launch_ms = a["traceMs"] / launches
-        t = entry("k_trace<closest>", a["traceMs"], batched * b_ray, batched, "ray", b_ray,
-                  nodes_per_ray=nodes, tris_per_ray=tris, max_nodes_one_ray=worst, rays_per_launch=batched / launches,
-                  launches_per_step=launches / steps, avg_launch_ms=avg_launch_ms, bytes_per_launch=batched / launches * b_ray)
-        # the honest ceiling: the algorithmic bytes are mostly cache hits (the tree lives in L2 / the Infinity Cache), so the
-        # HBM-side rate is the measured one, and what binds the kernel is the vector L1's lookup rate and VALU issue
-        t["algorithmic_note"] = ("achieved/frac count 64 B per node visit and 48 B per triangle test as if each came from HBM (SURVEY 8d's "
-                                 "contract); most are L2 / Infinity Cache hits -- see hbm_measured for the DRAM-side rate")
-        attach_traffic(t, "k_trace<closest>", avg_launch_ms if a["traceMs"] > 0 and batched > launches else 0.0)
-        t["binding_resource"] = "vector-L1 (TCP) lookups and VALU issue at partial lane utilisation, not HBM bytes (profiles/*_pmc_summary.txt)"
-        out.append(t)
+        out.append(entry("k_trace<closest>", a["traceMs"], batched * b_ray, batched, "ray", b_ray,
+                         nodes_per_ray=nodes, tris_per_ray=tris, max_nodes_one_ray=worst, rays_per_launch=batched / launches,
+                         launches_per_step=launches / steps, avg_launch_ms=avg_launch_ms, bytes_per_launch=batched / launches * b_ray))
         wpb = a["wavefrontPathBounces"]
         out.append(entry("k_shade_a<FAST+SLOW>", a["shadeAMs"], wpb * B_SHADE_A, wpb, "path-bounce", B_SHADE_A))
         out.append(entry("k_shade_b<FAST+SLOW>", a["shadeBMs"], wpb * B_SHADE_B, wpb, "path-bounce", B_SHADE_B))
@@ -206,44 +254,81 @@ class Run:
         out.append(entry("k_tail", a["tailMs"], tail_bytes, a["tailRays"], "ray (+ its share of the bounce's shading)",
                          tail_bytes / max(a["tailRays"], 1), paths_per_step=a["tailPaths"] / steps,
                          nodes_per_ray=tnodes, tris_per_ray=ttris,
-                         binding_resource="VALU issue (about 80 % busy) at about 29 of 64 lanes per instruction (profiles/*_pmc_summary.txt)",
                          note="one lane per path, the two rays of a bounce walked by the whole wave (DESIGN.md section 4); nodes / triangles per ray: "
                               "the counting build's figures for all rays of a sample minus those of the batched launches"))
-        attach_traffic(out[-1], "k_tail", a["tailMs"] / steps)
         return out
 
     def close(self):
         self.trace.close()
 
 
-def run_single(name, steps, warmup):
+def run_single(name, steps, warmup, release_scene=False):
     """a sub-record: the workload on one GPU, no collective"""
     r = Run(name)
     for i in range(warmup):
         r.step(i)
     r.trace.clear()
+    r.build_ms = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
         r.add(r.step(i))
     dt = time.perf_counter() - t0
+    r.build_ms_timed = r.build_ms
     a = r.acc
     rays = a["extensionRays"] + a["shadowRays"] + a["otherRays"]
     mean, stddev = r.trace.stddev()
     rec = {"workload": name, "scene_tris": r.sc.tri_count, "width": r.W, "height": r.H, "max_bounces": r.wl["bounces"], "steps": steps,
            "warmup": warmup, "value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3 / steps, "spp_per_s": steps / dt,
-           "rays_per_path": rays / (steps * r.W * r.H), "device_ms_per_step": a["totalMs"] / steps,
-           "image_mean_luminance": mean, "pt_stddev": stddev, "rooflines": r.rooflines(steps, dt * 1e3 / steps)}
+           "rays_per_path": rays / (steps * r.W * r.H), "device_ms_per_step": a["totalMs"] / steps, "traversal_ms_per_step": a["traceMs"] / steps,
+           "image_mean_luminance": mean, "pt_stddev": stddev}
+    if r.wl.get("rebuild"):
+        # config 5: a step is a FULL BVH rebuild plus one sample; the two parts are reported separately as BASELINE asks
+        info = r.scene.info()
+        rec["bvh_rebuild_ms_per_step"] = r.build_ms_timed / steps
+        rec["trace_only_Mrays_per_s"] = rays / (a["totalMs"] * 1e-3) / 1e6 if a["totalMs"] > 0 else None
+        rec["bvh_nodes"] = info.bvhNodeCount
+        rec["bvh_build_algorithmic_bytes_per_tri"] = 600.0
+        rec["bvh_build_GBps_algorithmic"] = r.sc.tri_count * 600.0 / (rec["bvh_rebuild_ms_per_step"] * 1e-3) / 1e9 if rec["bvh_rebuild_ms_per_step"] > 0 else None
+    rec["rooflines"] = r.rooflines(steps, dt * 1e3 / steps)
     r.close()
+    if release_scene:
+        _SCENES.pop(r.wl["scene"])[2].close()
     return rec
 
 
-def incoherent_microbench(log2_rays=26, reps=4):
+def microbench_roofline(name, n, dt, b_ray, alg, nodes, tris, worst):
+    """the one launch of the microbenchmark against the same three ceilings as the step's kernels (Run.rooflines)"""
+    pk = load_profile(name).get("k_trace") or {}
+    e = {"kernel": "k_trace<closest>", "algorithmic_bytes_per_ray": b_ray, "algorithmic_GBps": alg, "algorithmic_frac_of_hbm_peak": alg / HBM_PEAK_GBS,
+         "nodes_per_ray": nodes, "tris_per_ray": tris, "max_nodes_one_ray": worst, "traffic": None,
+         "ceilings": {"cache": {"achieved": alg, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": alg / L2_PEAK_GBS,
+                                "what": "algorithmic bytes (64 B per node visit, 48 B per triangle test) against the L2's aggregate bandwidth (a 1 M-triangle "
+                                        "tree, 67 MB, lives in L2 and the Infinity Cache; the 20 M-triangle one, 1.3 GB, does not: its binding ceiling is hbm)"}}}
+    src = f"profiles/traffic.json [{pk.get('tag')}] = rocprofv3 --pmc passes of `{pk.get('command')}` ({pk.get('summary_file')})"
+    if pk.get("valu_insts_per_unit"):
+        g = n * pk["valu_insts_per_unit"] / dt / 1e9
+        e["ceilings"]["valu"] = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
+                                 "wave_insts_per_unit": pk["valu_insts_per_unit"], "lanes_per_valu_inst": pk.get("lanes_per_valu_inst"),
+                                 "attainable_peak": VALU_ATTAINABLE_GINST, "frac_of_attainable": g / VALU_ATTAINABLE_GINST, "source": src}
+    if pk.get("hbm_bytes_per_unit") is not None:
+        g = n * pk["hbm_bytes_per_unit"] / dt / 1e9
+        e["ceilings"]["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "bytes_per_unit": pk["hbm_bytes_per_unit"],
+                                "l2_hit_rate": pk.get("l2_hit_rate"), "source": src}
+        e["traffic"] = n * pk["hbm_bytes_per_unit"]
+    measured = {k: v for k, v in e["ceilings"].items() if k != "cache"} or e["ceilings"]
+    name = max(measured, key=lambda k: measured[k]["frac"])
+    c = e["ceilings"][name]
+    e.update({"bound": name, "achieved": c["achieved"], "peak": c["peak"], "unit": c["unit"], "frac": c["frac"]})
+    return e
+
+
+def incoherent_microbench(log2_rays=26, reps=4, kind="synth1m", name="incoherent_closest_hit_1m"):
     """incoherent closest-hit rays -- origins uniformly on random triangles of the 1M-triangle scene (+1e-4 N),
     directions uniform in the hemisphere of the geometric normal, in random order; 2^26 rays, ONE launch of the traversal
     kernel through the C-ABI (pimgpu_intersect_packed_dev), rays and hits resident in HBM.  The rays are generated on the
     device (torch is used for device memory and random numbers only)."""
     import torch
-    sc, cam, scene = build_scene("synth1m")
+    sc, cam, scene = build_scene(kind)
     lib = api.load_library()
     dev = torch.device("cuda", 0)
     n = 1 << log2_rays
@@ -282,14 +367,10 @@ def incoherent_microbench(log2_rays=26, reps=4):
     rays = max(rays, 1)
     b_ray = 48.0 + 64.0 * nodes / rays + 48.0 * tris / rays
     ach = n * b_ray / dt / 1e9
-    rec = {"workload": "incoherent_closest_hit_1m", "scene_tris": sc.tri_count, "rays_per_launch": n, "launches_timed": reps,
+    rec = {"workload": name, "scene_tris": sc.tri_count, "rays_per_launch": n, "launches_timed": reps,
            "ms_per_launch": dt * 1e3, "value": n / dt / 1e6, "unit": "Mrays/s", "north_star_target_Mrays_per_s": 2000.0,
            "hit_fraction": float((hits[:, 0] >= 0).float().mean()),
-           "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_ray": b_ray, "nodes_per_ray": nodes / rays, "tris_per_ray": tris / rays, "max_nodes_one_ray": worst,
-                        "traffic": None,
-                        "algorithmic_note": "algorithmic bytes (64 B per node visit, 48 B per triangle test); the 67 MB tree is served from L2 / the "
-                                            "Infinity Cache, so a fraction near or above 1 is a cache-bandwidth statement, not DRAM traffic"}}
+           "roofline": microbench_roofline(name, n, dt, b_ray, ach, nodes / rays, tris / rays, worst)}
     del rayO, rayD, hits, pos
     torch.cuda.empty_cache()
     return rec
@@ -304,8 +385,13 @@ def main():
     ap.add_argument("--total-spp", type=int, default=0, help="strong scaling: this many samples in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (other workloads, microbenchmark)")
+    ap.add_argument("--plain", action="store_true", help="profiling target: warm-up + timed steps and nothing else (no counting frames, no CPU baseline, "
+                    "no sub-records), so that every frame a profiler sees is one step of the workload")
+    ap.add_argument("--microbench-only", action="store_true", help="profiling target: the incoherent-ray microbenchmark alone")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    if args.plain:
+        args.no_sub = args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,6 +411,15 @@ def main():
         torch.cuda.init()
         torch.zeros(1, device="cuda")
     api.init(local_rank if world > 1 else 0)
+    if args.microbench_only:
+        if wl["scene"] == "synth20m":
+            print(json.dumps(incoherent_microbench(24, 2, "synth20m", "incoherent_closest_hit_20m")), flush=True)
+        else:
+            print(json.dumps(incoherent_microbench(reps=2)), flush=True)
+        for sc_, cam_, scene_ in _SCENES.values():
+            scene_.close()
+        api.shutdown()
+        return
     run = Run(args.workload, rank, world)
     info = run.scene.info()
     W, H = run.W, run.H
@@ -337,8 +432,28 @@ def main():
         steps = args.steps
         my_samples = [pdist.sample_indices(rank, world, i + 1)[i] for i in range(steps)]
     reduce_buf = None
+    live_t = base_t = None
     if world > 1:
         reduce_buf = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        # the light histograms of the replicas are summed before every UpdateDists (pim_amd/dist.py): every rank then samples its
+        # lights from the distributions ONE process tracing all the ranks' paths would hold
+        nlive = max(1, run.scene.live_count())
+        live_t = torch.zeros(nlive, dtype=torch.int32, device="cuda")
+        base_t = torch.zeros(nlive, dtype=torch.int32, device="cuda")
+        run.scene.live_get_dev(base_t.data_ptr())
+
+    def step(i, sample):
+        """one step of this rank.  N > 1: all-reduce of the histogram increments, UpdateDists on the sum, this rank's sample"""
+        nonlocal live_t, base_t
+        if world == 1:
+            return run.step(i, sample)
+        run.scene.live_get_dev(live_t.data_ptr())
+        summed = pdist.allreduce_light_histograms(live_t, base_t, world, dist)
+        torch.cuda.current_stream().synchronize()            # the library copies on its own stream
+        run.scene.live_set_dev(summed.data_ptr())
+        run.scene.update_dists()
+        run.scene.live_get_dev(base_t.data_ptr())
+        return run.step(i, sample, update_dists=0)
 
     def sync():
         if world > 1:
@@ -347,12 +462,13 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        run.step(i)
+        step(i, None)
     run.trace.clear()
+    run.build_ms = 0.0
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
-        run.add(run.step(i, my_samples[i]))         # sampleWeight 1/(i+1): this rank's image is the running mean of ITS samples
+        run.add(step(i, my_samples[i]))             # sampleWeight 1/(i+1): this rank's image is the running mean of ITS samples
     if world > 1:
         # the path's one exchange step: sum of the per-GPU mean images on rank 0 (RCCL reduce over xGMI), weighted by the
         # number of samples each rank rendered
@@ -374,7 +490,7 @@ def main():
     if rank == 0:
         mean, stddev = run.trace.stddev()
         steps_r0 = max(steps, 1)
-        roofs = run.rooflines(steps_r0, dt * 1e3 / steps_r0)
+        roofs = run.rooflines(steps_r0, dt * 1e3 / steps_r0, plain=args.plain)
         dominant = max(roofs, key=lambda e: e["ms_per_step"])
         # the contract's `roofline` object is the dominant kernel's entry; `rooflines` has every kernel class of the step
         out = {
@@ -384,7 +500,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene_tris": info.triCount, "width": W, "height": H,
                        "max_bounces": wl["bounces"], "spp_per_step": 1,
-                       "sharding": ("sample ranges of --total-spp %d" % args.total_spp if strong else "sample index, interleaved") if world > 1 else "none"},
+                       "sharding": ("sample ranges of --total-spp %d" % args.total_spp if strong else "sample index, interleaved") if world > 1 else "none",
+                       "light_histograms": "SUM all-reduce of the ranks' increments before every UpdateDists" if world > 1 else "one replica"},
             "spp_per_s": total_steps / dt,
             "paths_per_s": total_steps * W * H / dt,
             "rays_per_path": rays / (steps_r0 * W * H),
@@ -403,6 +520,14 @@ def main():
             for name in ("cornell_1080p", "synth1m_1080p"):
                 if name != args.workload:
                     subs.append(run_single(name, 16, 3))
+            if args.workload != "synth20m_1080p" and not os.environ.get("PIM_BENCH_SKIP_20M"):
+                try:
+                    subs.append(run_single("synth20m_1080p", 8, 2))                          # config 5 on one GPU: the HBM-bound case
+                    subs.append(incoherent_microbench(24, 3, "synth20m", "incoherent_closest_hit_20m"))
+                except Exception as e:
+                    subs.append({"workload": "synth20m_1080p", "error": repr(e)})
+                if "synth20m" in _SCENES:
+                    _SCENES.pop("synth20m")[2].close()
             try:
                 subs.append(incoherent_microbench())
             except Exception as e:                      # a sub-record must not lose the headline line

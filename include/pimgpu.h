@@ -290,6 +290,15 @@ int pimgpu_scene_download_lights(const PimScene* scene,
     int32_t* vertToEmit, int32_t* emitToVert, int32_t* cellLength,
     float* pdf, float* cdf, uint32_t* live);
 
+/* The light histograms alone -- Dist1D.live of every grid cell, u32[gridLen * emissiveCount], the counters LightOnHit adds to
+ * with relaxed atomics (path_tracer.c:1709-1733) and UpdateDists folds into the pdfs (:2460-2483, math/dist1d.c:128-163) --
+ * copied device-to-device to / from caller-owned HBM.  The reference has one PtScene per process; with one PROCESS per GPU
+ *  every replica collects its own increments, and summing them over the ranks (RCCL all-reduce of live - base)
+ * before pimgpu_scene_update_dists keeps every replica's sampling distributions equal to the ones a single process tracing all
+ * the paths would hold (pim_amd/dist.py, bench.py --gpus N).  A device LIST inside one process does this itself. */
+int pimgpu_scene_live_get_dev(const PimScene* scene, void* dstDev);
+int pimgpu_scene_live_set_dev(PimScene* scene, const void* srcDev);
+
 /* ---- rays ---------------------------------------------------------------- */
 
 /* batched Pt_Intersect (path_tracer.c:1466-1474, pt_intersect_local :1421-1464);

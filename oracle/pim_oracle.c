@@ -805,6 +805,12 @@ void orc_scene_download_lights(const OrcScene* s, int32_t* vertToEmit, int32_t* 
     if (live) memcpy(live, s->live, sizeof(uint32_t) * (size_t)s->gridLen * E);
 }
 
+/* test plumbing of the one-process-per-GPU form: the light histograms as a rank's all-reduce leaves them */
+void orc_scene_set_live(OrcScene* s, const uint32_t* live)
+{
+    memcpy(s->live, live, sizeof(uint32_t) * (size_t)s->gridLen * (size_t)s->emissiveCount);
+}
+
 /* UpdateDists, pt.c:2460-2483 */
 void orc_scene_update_dists(OrcScene* s)
 {

@@ -111,7 +111,7 @@ assert RAYHIT_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 36 and C.sizeof(
 EXPORTS = [
     "pimgpu_init", "pimgpu_shutdown", "pimgpu_last_error", "pimgpu_host_alloc", "pimgpu_host_free",
     "pimgpu_scene_create", "pimgpu_scene_destroy", "pimgpu_scene_rebuild_bvh", "pimgpu_scene_update_dists",
-    "pimgpu_scene_info", "pimgpu_scene_download_lights",
+    "pimgpu_scene_info", "pimgpu_scene_download_lights", "pimgpu_scene_live_get_dev", "pimgpu_scene_live_set_dev",
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
     "pimgpu_trace_download", "pimgpu_trace_image_host", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
@@ -186,6 +186,17 @@ class Scene:
 
     def update_dists(self):
         check(self.lib.pimgpu_scene_update_dists(self.handle), "pimgpu_scene_update_dists")
+
+    def live_count(self):
+        info = self.info()
+        return info.gridLen * info.emissiveCount
+
+    def live_get_dev(self, dst_ptr):
+        """the light histograms (u32[gridLen * E]) into caller-owned HBM"""
+        check(self.lib.pimgpu_scene_live_get_dev(self.handle, C.c_void_p(dst_ptr)), "pimgpu_scene_live_get_dev")
+
+    def live_set_dev(self, src_ptr):
+        check(self.lib.pimgpu_scene_live_set_dev(self.handle, C.c_void_p(src_ptr)), "pimgpu_scene_live_set_dev")
 
     def download_lights(self):
         info = self.info()

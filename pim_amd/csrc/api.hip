@@ -572,6 +572,30 @@ int pimgpu_scene_update_dists(PimScene* scene)
     return PIMGPU_OK;
 }
 
+/* the light histograms (LightOnHit's feedback, path_tracer.c:1709-1733) to and from caller-owned HBM: what one process per GPU
+ * exchanges before UpdateDists -- u32[gridLen * emissiveCount], device-to-device on the library's stream */
+int pimgpu_scene_live_get_dev(const PimScene* s, void* dstDev)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!s || !dstDev) { set_error("scene_live_get_dev: NULL argument"); return PIMGPU_E_INVALID; }
+    if (g_libCount > 1 && s->peers[1]) { set_error("scene_live_get_dev: a device list sums its replicas' histograms itself"); return PIMGPU_E_STATE; }
+    const size_t bytes = sizeof(uint32_t) * (size_t)s->d.gridLen * (size_t)s->d.emissiveCount;
+    if (bytes) PT_HIP(hipMemcpyAsync(dstDev, s->live, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
+int pimgpu_scene_live_set_dev(PimScene* s, const void* srcDev)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!s || !srcDev) { set_error("scene_live_set_dev: NULL argument"); return PIMGPU_E_INVALID; }
+    if (g_libCount > 1 && s->peers[1]) { set_error("scene_live_set_dev: a device list sums its replicas' histograms itself"); return PIMGPU_E_STATE; }
+    const size_t bytes = sizeof(uint32_t) * (size_t)s->d.gridLen * (size_t)s->d.emissiveCount;
+    if (bytes) PT_HIP(hipMemcpyAsync(s->live, srcDev, bytes, hipMemcpyDeviceToDevice, g_lib.stream));
+    PT_HIP(hipStreamSynchronize(g_lib.stream));
+    return PIMGPU_OK;
+}
+
 int pimgpu_scene_info(const PimScene* s, PimSceneInfo* out)
 {
     if (!s || !out) { set_error("scene_info: NULL argument"); return PIMGPU_E_INVALID; }

@@ -1,5 +1,7 @@
 """Multi-GPU plumbing of the path: one process per GPU, the scene replicated, work sharded
-with no data-path collective except ONE reduce of the accumulated images at read-back time.
+with no data-path collective except ONE reduce of the accumulated images at read-back time and, once per step, the
+SUM all-reduce of the light-histogram increments (cells x emissives x 4 bytes) that keeps every replica's sampling
+distributions equal to a single process's.
 
   image path   : samples sharded by index -- rank r of N renders samples r, r+N, r+2N, ...; each rank keeps its
                  own running-mean image; the mean over ranks (equal sample counts) is one SUM reduce / N
@@ -56,3 +58,17 @@ def reduce_mean_image(tensor, world, dist, dst=0, weight=None, total=None):
         if equal and dist.get_rank() == dst:
             tensor.mul_(1.0 / world)
     return tensor
+
+
+def allreduce_light_histograms(live, base, world, dist):
+    """LightOnHit's feedback (path_tracer.c:1709-1733) lands in the replica of the rank that traced the path.  Before
+    UpdateDists every rank therefore adds the increments the OTHER ranks made since the last UpdateDists:
+    live' = base + SUM over ranks of (live - base), base = the histograms as the last UpdateDists left them (identical on all
+    ranks).  Integer adds, so live' is exactly what one process tracing all the ranks' paths would hold, on every rank;
+    UpdateDists then gives every replica the same pdf / cdf bit for bit.  `live`, `base`: int32 tensors (u32 bits; the
+    arithmetic wraps the same way) on the collective's device.  Returns live'."""
+    if world <= 1:
+        return live
+    delta = live - base
+    dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+    return base + delta

@@ -87,6 +87,67 @@ def test_1m_scene_image_bit_exact(big):
     t.close()
 
 
+def _frames_bit_exact(g, o, cam, W, H, frames, max_bounces, seed):
+    """`frames` accumulated samples of a W x H image on both sides: every pixel of the three images, the ray counts, the
+    autofocus state and the light histograms, bit for bit"""
+    t = api.Trace(W, H)
+    img = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dg, do = scenes.default_dof(), scenes.default_dof()
+    stats = []
+    for s in range(frames):
+        p = scenes.trace_params(s, seed=seed, max_bounces=max_bounces)
+        t.trace(g, cam, dg, p)
+        so = o.trace_image(img, W, H, cam, do, p)
+        sg = t.stats()
+        assert (sg.extensionRays, sg.shadowRays, sg.otherRays, sg.paths) == (so.extensionRays, so.shadowRays, so.otherRays, so.paths), f"frame {s}"
+        assert dg.focalLength == do.focalLength
+        stats.append(sg)
+    color, albedo, normal = t.download()
+    assert_bits_equal(color, img[0], "color"); assert_bits_equal(albedo, img[1], "albedo"); assert_bits_equal(normal, img[2], "normal")
+    assert t.stddev() == o.stddev(img[0], W, H)
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("live", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k)
+    t.close()
+    return stats
+
+
+def test_bench_workload_synth1m_4k_default_policy_bit_exact(monkeypatch):
+    """bench.py's headline workload at its own size and under the library's OWN tail policy (no switch forced): the 1 M-triangle
+    scene exactly as bench.build_scene makes it, 3840 x 2160, 8-bounce clamp, two frames -- the first has no queue-length history
+    (every bounce a wavefront bounce, parked paths finished by the tail kernel), the second takes tail_policy's history branch
+    (wavefront bounces until fewer than 2.5 M paths are left, then k_tail).  8.3 M paths per frame, 5.4 M-ray launches in
+    128-ray dynamic chunks; the oracle needs about 5 s per frame on 16 threads."""
+    for k in ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_FRACTION", "PIMGPU_TAIL_MAX_PATHS", "PIMGPU_PARK", "PIMGPU_NEE_TARGET", "PIMGPU_TRACE_CHUNK", "PIMGPU_GROUPS"):
+        monkeypatch.delenv(k, raising=False)
+    gpu_init()
+    sc = scenes.synthetic_scene(target_tris=1_000_000, seed=1234, extent=100.0, emissive_attempts=64)       # bench.build_scene("synth1m")
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    try:
+        st = _frames_bit_exact(g, o, scenes.synthetic_camera(100.0), 3840, 2160, 2, 8, seed=1)
+        assert st[0].bounces == 8 and st[0].tailPaths == 0                   # no history: the wavefront ran to the clamp
+        assert 0 < st[1].bounces < 8 and 0 < st[1].tailPaths < 2_500_000      # history: the tail kernel took the short queue over
+    finally:
+        g.close(); o.close()
+
+
+def test_bench_workload_cornell_1080p_8_bounces_bit_exact(monkeypatch):
+    """BASELINE config 2 at its own size: cornell_box, 1920 x 1080, the 8-bounce clamp, two accumulated frames under the default
+    policy (2.07 M paths: the whole integrator runs as one k_tail launch)"""
+    for k in ("PIMGPU_TAIL_BOUNCE", "PIMGPU_TAIL_FRACTION", "PIMGPU_TAIL_MAX_PATHS", "PIMGPU_PARK", "PIMGPU_NEE_TARGET", "PIMGPU_TAIL_DENSE"):
+        monkeypatch.delenv(k, raising=False)
+    gpu_init()
+    sc = scenes.cornell_box()
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    try:
+        st = _frames_bit_exact(g, o, scenes.pt_test_camera(), 1920, 1080, 2, 8, seed=1)
+        assert st[1].bounces == 0 and st[1].tailPaths == 1920 * 1080
+    finally:
+        g.close(); o.close()
+
+
 def test_embed_full_size_pages_spot_checked_and_idempotent():
     """EmbedAttributes at bake scale (2 pages of 1024^2, 120 k mapped triangles): the oracle's per-texel loop on 3000 texels
     picked at random and on every texel of two rows, bit for bit; sampleCounts is 0 or 1; a second call gives the same pages"""

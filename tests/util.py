@@ -74,6 +74,10 @@ class OracleScene:
     def update_dists(self):
         self.lib.orc_scene_update_dists(self.handle)
 
+    def set_live(self, live):
+        live = np.ascontiguousarray(live, np.uint32)
+        self.lib.orc_scene_set_live(self.handle, _p(live))
+
     def intersect(self, ro, rd, tNear=None, tFar=None):
         ro, rd = api.f32(ro), api.f32(rd)
         n = ro.shape[0]
