@@ -78,7 +78,7 @@ static void scene_free(PimScene* s)
 {
     if (!s) return;
     hipFree(s->positions); hipFree(s->normals); hipFree(s->uvs); hipFree(s->matIds);
-    hipFree(s->vertToEmit); hipFree(s->emitToVert); hipFree(s->materials); hipFree(s->textures);
+    hipFree(s->vertToEmit); hipFree(s->emitToVert); hipFree(s->tri); hipFree(s->materials); hipFree(s->textures);
     for (void* p : s->texels) hipFree(p);
     for (int f = 0; f < 6; ++f) hipFree(s->sky[f]);
     hipFree(s->lut);
@@ -449,6 +449,10 @@ static int scene_create_one(const PimSceneDesc* d, PimScene** out)
     media_from_desc(&s->d.media, &d->media);
     s->d.positions = s->positions; s->d.normals = s->normals; s->d.uvs = s->uvs; s->d.matIds = s->matIds;
     s->d.materials = s->materials; s->d.textures = s->textures;
+    /* the shading stages' per-triangle records, before anything that classifies a hit (the light-grid set-up does) */
+    if ((rc = upload(&s->tri, nullptr, (size_t)s->d.triCount))) return fail(rc);
+    if ((rc = pack_trirecs(s->d, s->tri, g_lib.stream))) return fail(rc);
+    s->d.tri = s->tri;
 
     hipEvent_t e0, e1;
     PT_HIP(hipEventCreate(&e0)); PT_HIP(hipEventCreate(&e1));

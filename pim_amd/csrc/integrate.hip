@@ -463,7 +463,8 @@ __device__ __forceinline__ StageAOut stage_a(const DScene& s, const StageArgs& a
                                     if (PRE && a.neeTarget)
                                     {
                                         const RayPre rp = ray_pre(nO.x, nO.y, nO.z, nD.x, nD.y, nD.z);
-                                        const v4 A = s.positions[iVert + 0], B = s.positions[iVert + 1], C = s.positions[iVert + 2];
+                                        const DTriRec* lt = tri_of(s, iVert);
+                                        const v4 A = lt->p0, B = lt->p1, C = lt->p2;
                                         float t, vn, wn, det;
                                         out.target = iVert / 3;
                                         if (tri_test_raw(rp, make_float4(A.x, A.y, A.z, 0.0f), make_float4(B.x, B.y, B.z, 0.0f), make_float4(C.x, C.y, C.z, 0.0f), 0.0f, nD.w, &t, &vn, &wn, &det))

@@ -17,6 +17,7 @@ struct PimScene
     /* owned device memory */
     pt::v4* positions = nullptr; pt::v4* normals = nullptr; pt::v2* uvs = nullptr; int32_t* matIds = nullptr;
     int32_t* vertToEmit = nullptr; int32_t* emitToVert = nullptr;
+    pt::DTriRec* tri = nullptr;          /* per-triangle records of the shading stages (pt_device.h) */
     PimMaterial* materials = nullptr; pt::DTexture* textures = nullptr;
     std::vector<void*> texels;
     pt::v3* sky[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -155,6 +156,7 @@ inline void band_of(int32_t height, int i, int G, int32_t* rowBegin, int32_t* ro
 int for_each_context(int count, const std::function<int(int)>& fn);
 
 /* setup.hip */
+int pack_trirecs(const DScene& s, DTriRec* out, hipStream_t stream);
 int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float* pdfsDev, hipStream_t stream);
 int setup_light_grid(const DScene& s, TraceResources* res, float metersPerCell, uint32_t seed, int32_t* cellLengthDev, hipStream_t stream);
 int update_dists(const DScene& s, hipStream_t stream);

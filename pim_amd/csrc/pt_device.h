@@ -79,11 +79,30 @@ struct DBvh
     int32_t triCount;
 };
 
+/*
+ * One triangle as the shading stages read it: the three vertices' positions, normals and uvs, the material id and the
+ * material's flags, copied from the PtScene arrays (same bits) into ONE 128-byte, 128-byte-aligned record = one cache line.
+ * GetSurface needs 3 x (16 + 16 + 8) + 4 bytes of a hit triangle; from the reference's four separate arrays (48-, 48-, 24- and
+ * 12-byte strides per triangle) an incoherent hit touches 6-7 memory sectors in four lines, from the record two sectors of one
+ * line -- the stages are bound by HBM-side traffic at 1.6-1.8 x their algorithmic bytes (profiles/r03_synth1m_4k_*).
+ * The arrays themselves stay: they are the upload format and what the set-up kernels read.
+ */
+struct __attribute__((aligned(128))) DTriRec
+{
+    v4 p0, p1, p2;
+    v4 n0, n1, n2;
+    v2 uv0, uv1, uv2;
+    int32_t matId;          /* matIds[3 * tri] */
+    uint32_t flags;         /* materials[matId].flags */
+};
+static_assert(sizeof(DTriRec) == 128, "one cache line per triangle");
+
 struct DScene
 {
     int32_t vertCount, triCount, matCount, texCount, emissiveCount;
     const v4* positions; const v4* normals; const v2* uvs; const int32_t* matIds;
     const int32_t* vertToEmit; const int32_t* emitToVert;
+    const DTriRec* tri;         /* [triCount], built from the four arrays above at scene creation */
     const PimMaterial* materials;
     const DTexture* textures;
     int32_t skySize; const v3* sky[6];

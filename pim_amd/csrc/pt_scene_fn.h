@@ -103,9 +103,9 @@ __device__ __forceinline__ RayHit make_rayhit(const DScene& s, v4 rd, DHit h)
     hit.normal = f4_s(0.0f);
     hit.type = PIM_HIT_NOTHING; hit.iVert = -1; hit.flags = 0;
     if (h.prim < 0 || h.t <= 0.0f) return hit;
-    const v4* p = s.positions + (size_t)h.prim * 3;
-    const v4 p0 = p[0];
-    v4 e1 = f4_sub(p[1], p0), e2 = f4_sub(p[2], p0);
+    const DTriRec* r = s.tri + h.prim;
+    const v4 p0 = r->p0;
+    v4 e1 = f4_sub(r->p1, p0), e2 = f4_sub(r->p2, p0);
     e1.w = e2.w = 0.0f;
     v4 Ng = f4_cross3(e1, e2);
     hit.type = PIM_HIT_TRIANGLE;
@@ -115,7 +115,7 @@ __device__ __forceinline__ RayHit make_rayhit(const DScene& s, v4 rd, DHit h)
     const float u = f1_sat(h.u), v = f1_sat(h.v), w = f1_sat(1.0f - (u + v));
     hit.iVert = h.prim * 3;
     hit.wuvt = f4_v(w, u, v, h.t);
-    hit.flags = s.materials[s.matIds[hit.iVert]].flags;
+    hit.flags = r->flags;
     return hit;
 }
 __device__ __forceinline__ int32_t hit_type(const DScene& s, v4 rd, DHit h) { return make_rayhit(s, rd, h).type; }
@@ -166,15 +166,18 @@ __device__ __forceinline__ v4 GetSky(const DScene& s, v4 rd)                    
     }
     return f4_s(0.0f);
 }
-__device__ __forceinline__ v2 GetUV(const DScene& s, const RayHit& hit) { return f2_blend(s.uvs[hit.iVert + 0], s.uvs[hit.iVert + 1], s.uvs[hit.iVert + 2], hit.wuvt); }
-__device__ __forceinline__ v4 GetPosition(const DScene& s, const RayHit& hit) { return f4_blend(s.positions[hit.iVert + 0], s.positions[hit.iVert + 1], s.positions[hit.iVert + 2], hit.wuvt); }
+/* the hit triangle's record (pt_device.h): iVert == 3 * primID everywhere */
+__device__ __forceinline__ const DTriRec* tri_of(const DScene& s, int32_t iVert) { return s.tri + (uint32_t)iVert / 3u; }
+__device__ __forceinline__ v2 GetUV(const DScene& s, const RayHit& hit) { const DTriRec* r = tri_of(s, hit.iVert); return f2_blend(r->uv0, r->uv1, r->uv2, hit.wuvt); }
+__device__ __forceinline__ v4 GetPosition(const DScene& s, const RayHit& hit) { const DTriRec* r = tri_of(s, hit.iVert); return f4_blend(r->p0, r->p1, r->p2, hit.wuvt); }
 __device__ __forceinline__ v4 GetNormal(const DScene& s, const RayHit& hit)          /* pt.c:1192-1204 */
 {
-    v4 N = f4_blend(s.normals[hit.iVert + 0], s.normals[hit.iVert + 1], s.normals[hit.iVert + 2], hit.wuvt);
+    const DTriRec* r = tri_of(s, hit.iVert);
+    v4 N = f4_blend(r->n0, r->n1, r->n2, hit.wuvt);
     N = (f4_dot3(hit.normal, N) > 0.0f) ? N : f4_neg(N);
     return f4_normalize3(N);
 }
-__device__ __forceinline__ float GetArea(const DScene& s, int32_t iVert) { return TriArea3D(s.positions[iVert + 0], s.positions[iVert + 1], s.positions[iVert + 2]); }
+__device__ __forceinline__ float GetArea(const DScene& s, int32_t iVert) { const DTriRec* r = tri_of(s, iVert); return TriArea3D(r->p0, r->p1, r->p2); }
 
 __device__ __forceinline__ v4 tex_c32(const DScene& s, int32_t id, v2 uv, v4 dflt)
 {
@@ -186,7 +189,7 @@ __device__ __forceinline__ v4 tex_c32(const DScene& s, int32_t id, v2 uv, v4 dfl
 __device__ __forceinline__ v4 GetEmission(const DScene& s, v4 rd, const RayHit& hit)   /* pt.c:1293-1326 */
 {
     if (hit.flags & PIM_MATFLAG_SKY) return GetSky(s, rd);
-    const PimMaterial* mat = &s.materials[s.matIds[hit.iVert]];
+    const PimMaterial* mat = &s.materials[tri_of(s, hit.iVert)->matId];
     const int32_t albedoId = mat->albedo, romeId = mat->rome;
     const v2 uv = GetUV(s, hit);
     const v4 albedo = tex_c32(s, albedoId, uv, f4_s(1.0f));
@@ -201,7 +204,7 @@ __device__ __forceinline__ SurfHit GetSurface(const DScene& s, v4 rd, const RayH
 {
     SurfHit surf;
     surf.type = hit.type;
-    const PimMaterial mat = s.materials[s.matIds[hit.iVert]];
+    const PimMaterial mat = s.materials[tri_of(s, hit.iVert)->matId];
     surf.flags = mat.flags;
     surf.ior = mat.ior;
     const v2 uv = GetUV(s, hit);
@@ -517,7 +520,8 @@ __device__ __forceinline__ LightRay SampleLight_ray(Ctx& ctx, const DScene& s, v
 {
     LightRay lr;
     const v4 wuv = SampleBaryCoord(Sample2D(ctx));
-    const v4 A = s.positions[iVert + 0], B = s.positions[iVert + 1], C = s.positions[iVert + 2];
+    const DTriRec* lt = tri_of(s, iVert);
+    const v4 A = lt->p0, B = lt->p1, C = lt->p2;
     const v4 pt = f4_blend(A, B, C, wuv);
     v4 rd = f4_sub(pt, ro);
     lr.distSq = f4_dot3(rd, rd);

@@ -40,6 +40,29 @@ __global__ __launch_bounds__(256) void k_emission_pdf(DScene s, int32_t attempts
     pdfs[iTri] = pdf;
 }
 
+/* the per-triangle records of the shading stages (pt_device.h, DTriRec): the same bits as the PtScene arrays, one line per triangle */
+__global__ __launch_bounds__(256) void k_pack_trirecs(DScene s, DTriRec* __restrict__ out)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= s.triCount) return;
+    const int32_t iVert = t * 3;
+    DTriRec r;
+    r.p0 = s.positions[iVert + 0]; r.p1 = s.positions[iVert + 1]; r.p2 = s.positions[iVert + 2];
+    r.n0 = s.normals[iVert + 0]; r.n1 = s.normals[iVert + 1]; r.n2 = s.normals[iVert + 2];
+    r.uv0 = s.uvs[iVert + 0]; r.uv1 = s.uvs[iVert + 1]; r.uv2 = s.uvs[iVert + 2];
+    r.matId = s.matIds[iVert];
+    r.flags = s.materials[r.matId].flags;
+    out[t] = r;
+}
+
+int pack_trirecs(const DScene& s, DTriRec* out, hipStream_t stream)
+{
+    if (s.triCount <= 0) return PIMGPU_OK;
+    k_pack_trirecs<<<(s.triCount + 255) / 256, 256, 0, stream>>>(s, out);
+    PT_HIP(hipGetLastError());
+    return PIMGPU_OK;
+}
+
 int setup_emission_pdfs(const DScene& s, int32_t attempts, uint32_t seed, float* pdfsDev, hipStream_t stream)
 {
     if (s.triCount <= 0) return PIMGPU_OK;

@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void k_make_rayhits(DScene s, const float4* __
     {
         const float4 rd4 = rayD[i];
         const v4 rd = f4_v(rd4.x, rd4.y, rd4.z, 0.0f);
-        const v4* p = s.positions + (size_t)h.prim * 3;
-        v4 e1 = f4_sub(p[1], p[0]), e2 = f4_sub(p[2], p[0]);
+        const DTriRec* r = s.tri + h.prim;
+        v4 e1 = f4_sub(r->p1, r->p0), e2 = f4_sub(r->p2, r->p0);
         e1.w = e2.w = 0.0f;
         v4 Ng = f4_cross3(e1, e2);
         hit.type = PIM_HIT_TRIANGLE;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_make_rayhits(DScene s, const float4* __
         const float u = f1_sat(h.u), v = f1_sat(h.v), w = f1_sat(1.0f - (u + v));
         hit.iVert = h.prim * 3;
         hit.wuvt[0] = w; hit.wuvt[1] = u; hit.wuvt[2] = v; hit.wuvt[3] = h.t;
-        hit.flags = s.materials[s.matIds[hit.iVert]].flags;
+        hit.flags = r->flags;
     }
     out[i] = hit;
 }
