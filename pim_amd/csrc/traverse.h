@@ -222,22 +222,24 @@ struct TrivialStack
  * and the compiler cannot fold the two into one generic-address access */
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(1))) unsigned long long glb_u64;
-struct LdsStack
+/* LDSN: entries of a lane kept in LDS (the kernels' LdsStack has PT_STACK_LDS; the queued batched kernel of trace.hip fewer) */
+template <int LDSN>
+struct LdsStackT
 {
     lds_u64* lds;               /* &shared[threadIdx.x], stride ldsStride */
     glb_u64* spill;             /* &spill[global lane slot], stride spillStride */
     int ldsStride;
     int64_t spillStride;
     int sp;
-    int cap;                    /* entries the stack may hold: PT_STACK_MAX, or fewer (>= PT_STACK_LDS) when a test lowers it
+    int cap;                    /* entries the stack may hold: PT_STACK_MAX, or fewer (>= LDSN) when a test lowers it
                                    (PIMGPU_STACK_CAP) to exercise the overflow report without a 64-level tree */
     __device__ __forceinline__ static unsigned long long pack(float t, int32_t c) { return ((unsigned long long)(uint32_t)c << 32) | (unsigned long long)__float_as_uint(t); }
     __device__ __forceinline__ void init() { sp = 0; }
     __device__ __forceinline__ bool push(float t, int32_t c)
     {
         if (sp >= cap) return false;
-        if (sp < PT_STACK_LDS) lds[sp * ldsStride] = pack(t, c);
-        else spill[(int64_t)(sp - PT_STACK_LDS) * spillStride] = pack(t, c);
+        if (sp < LDSN) lds[sp * ldsStride] = pack(t, c);
+        else spill[(int64_t)(sp - LDSN) * spillStride] = pack(t, c);
         ++sp;
         return true;
     }
@@ -247,8 +249,8 @@ struct LdsStack
         --sp;
         /* the LDS read is unconditional (clamped slot) and the rare spill read sits under its own branch, so the
          * common case is one ds_read_b64 and never a generic-address load */
-        unsigned long long v = lds[(sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1) * ldsStride];
-        if (sp >= PT_STACK_LDS) v = spill[(int64_t)(sp - PT_STACK_LDS) * spillStride];
+        unsigned long long v = lds[(sp < LDSN ? sp : LDSN - 1) * ldsStride];
+        if (sp >= LDSN) v = spill[(int64_t)(sp - LDSN) * spillStride];
         *t = __uint_as_float((uint32_t)v); *c = (int32_t)(v >> 32);
         return true;
     }
@@ -264,7 +266,7 @@ struct LdsStack
     {
         const float inf = __builtin_inff();
         const int n = (d1 < inf ? 1 : 0) + (d2 < inf ? 1 : 0) + (d3 < inf ? 1 : 0);
-        if (sp + n <= PT_STACK_LDS)
+        if (sp + n <= LDSN)
         {
             if (n >= 3) lds[sp * ldsStride] = pack(d3, c3);
             if (n >= 2) lds[(sp + n - 2) * ldsStride] = pack(d2, c2);
@@ -279,6 +281,8 @@ struct LdsStack
         return ok;
     }
 };
+
+typedef LdsStackT<PT_STACK_LDS> LdsStack;
 
 #define PT_SWAP_IF(da, ca, db, cb) { const bool s_ = (db) < (da); const float td_ = s_ ? (db) : (da); const float tD_ = s_ ? (da) : (db); \
     const int32_t tc_ = s_ ? (cb) : (ca); const int32_t tC_ = s_ ? (ca) : (cb); (da) = td_; (db) = tD_; (ca) = tc_; (cb) = tC_; }
