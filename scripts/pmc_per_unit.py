@@ -47,11 +47,20 @@ def totals(src, last=None, skip_frames=0):
     return acc
 
 
-for wl in sys.argv[2:]:
+# --on-box: run where the counter CSVs are (they are too large to travel back): leaves <src>/per_unit.json, which a later run
+# of this script without the flag merges into profiles/traffic.json together with the text summaries
+on_box = "--on-box" in sys.argv
+args = [a for a in sys.argv[2:] if a != "--on-box"]
+for wl in args:
     src = os.path.join(root, "gpurun_out", f"prof_{tag}_{wl}")
-    for name in ("kernel_stats.txt", "pmc_summary.txt", "bench_line.json"):
-        if os.path.exists(os.path.join(src, name)):
-            shutil.copy(os.path.join(src, name), os.path.join(root, "profiles", f"{tag}_{wl}_{name}"))
+    if not on_box:
+        for name in ("kernel_stats.txt", "pmc_summary.txt", "bench_line.json"):
+            if os.path.exists(os.path.join(src, name)):
+                shutil.copy(os.path.join(src, name), os.path.join(root, "profiles", f"{tag}_{wl}_{name}"))
+        pu = os.path.join(src, "per_unit.json")
+        if os.path.exists(pu) and not glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+            traffic[wl] = json.load(open(pu))
+            continue
     line = json.load(open(os.path.join(src, "pmc_line.json")))          # the bench line of a PMC pass: its steps / warmup / units
     if "rooflines" in line:
         frames = line["steps"]                                            # the timed steps only
@@ -88,5 +97,8 @@ for wl in sys.argv[2:]:
             e["sq_active_inst_valu_total"] = t["SQ_ACTIVE_INST_VALU"][1]
         per[c] = e
     traffic[wl] = {"tag": tag, "kernels": per}
-json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
-print(json.dumps({k: traffic[k] for k in sys.argv[2:]}, indent=1))
+    if on_box:
+        json.dump(traffic[wl], open(os.path.join(src, "per_unit.json"), "w"), indent=1, sort_keys=True)
+if not on_box:
+    json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: traffic[k] for k in args}, indent=1))

@@ -21,4 +21,7 @@ python3 scripts/rocpd_summary.py $(find $out/kt -name "*.db" | head -1) $steps $
 python3 scripts/pmc_summary.py $out/pmc_* | grep -E "k_trace|k_shade|k_tail|k_init_image|k_resolve_image" > $out/pmc_summary.txt
 grep -h -E '"metric"|"workload"' $out/kt.log | tail -1 > $out/bench_line.json
 grep -h -E '"metric"|"workload"' $out/pmc_FETCH_SIZE.log | tail -1 > $out/pmc_line.json
+# the counter CSVs and the trace database stay on the box (gpurun_out/ travels back up to 64 MiB): their figures per unit of work now
+python3 scripts/pmc_per_unit.py $tag --on-box $wl > $out/per_unit.log 2>&1
+rm -rf $out/kt $out/pmc_*/
 echo done $wl
