@@ -12,14 +12,22 @@ Workloads (BASELINE.json configs):
   synth1m_1080p   the same scene at 1920x1080
   cornell_1080p   config #2: cornell_box, 1920x1080, 8-bounce clamp, pt_test camera
   cornell_360p    config #1 shape (640x360, 4 bounces) -- the CPU-runnable case
+  synth20m_1080p  config #5 on one GPU: 20M-triangle diffuse scene, the BVH rebuilt inside every timed step
 
-At N = 1 the line also carries, as sub-records ("other_workloads"), cornell_1080p, synth1m_1080p and the north
-star's incoherent-ray microbenchmark (2^26 shuffled surface rays into the 1M-triangle tree, one
-closest-hit launch); --no-sub skips them.
+At N = 1 the line also carries, as sub-records ("other_workloads"), cornell_1080p, synth1m_1080p, synth20m_1080p and the
+north star's incoherent-ray microbenchmark (shuffled surface rays in one closest-hit launch) on the 1M-triangle
+tree (2^26 rays) and on the 20M-triangle tree (2^24 rays); --no-sub skips them, PIM_BENCH_SKIP_20M=1 skips the 20M pair.
+--plain: no counting-build frame and no sub-records (what the profiler scripts run); --microbench-only: the two
+microbenchmarks alone.
+
+Every kernel entry of "rooflines" has three ceilings (valu issue / HBM-side bytes / algorithmic bytes against L2) and names
+the binding one in "bound"; the instruction and byte counts per unit come from the committed PMC runs (profiles/traffic.json,
+scripts/profile_bench.sh) and are scaled by this run's units and device time -- DESIGN.md section 5.
 
 Multi-GPU (N > 1, one process per GPU under torch.distributed.run, RCCL): the scene is replicated, samples are
-sharded by index, and the ONE exchange step of the path -- the sum of the per-GPU mean images onto rank 0 -- is an
-RCCL reduce inside the timed region.  Default: rank r renders samples r, r+N, ... for K steps each (per-GPU work fixed,
+sharded by index, and the exchange steps of the path -- the sum of the per-GPU mean images onto rank 0 and, after every
+step, the SUM all-reduce of the ranks' light-histogram increments (so that every rank samples lights as one process that
+had traced all samples would) -- are RCCL collectives inside the timed region.  Default: rank r renders samples r, r+N, ... for K steps each (per-GPU work fixed,
 "weak").  --total-spp S (config 3's "64 spp sharded"): the S samples are split over the ranks, rank r renders
 [r*S/N, (r+1)*S/N) ("strong"; --steps is then S/N per rank).  value = rays traced by all ranks / max-over-ranks time.
 
@@ -222,7 +230,7 @@ class Run:
                     g = units * pk["hbm_bytes_per_unit"] / sec / 1e9
                     ceilings["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                        "bytes_per_unit": pk["hbm_bytes_per_unit"], "l2_hit_rate": pk.get("l2_hit_rate"),
-                                       "what": "HBM-side bytes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)", "source": src}
+                                       "what": "HBM-side bytes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; counted between L2 and the fabric, so Infinity-Cache hits are included)", "source": src}
                     e["traffic"] = units / steps * pk["hbm_bytes_per_unit"]          # HBM-side bytes per step of this kernel class
                     if not plain and bytes_per_unit > 0:
                         e["traffic_over_algorithmic"] = pk["hbm_bytes_per_unit"] / bytes_per_unit
