@@ -409,8 +409,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PIM_BENCH_REHEARSE_GLOO"):
+            # rehearsal of the N-process control flow on a box with fewer GPUs than ranks: the ranks share the devices and the
+            # collectives run over gloo through host copies (pim_amd/dist.py).  Timings of such a run mean nothing.
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if world == 1 and not args.no_sub:
         # the microbenchmark leg keeps its rays in torch tensors; torch's HIP runtime has to come up BEFORE libpimgpu's
@@ -450,17 +457,21 @@ def main():
         base_t = torch.zeros(nlive, dtype=torch.int32, device="cuda")
         run.scene.live_get_dev(base_t.data_ptr())
 
-    def step(i, sample):
-        """one step of this rank.  N > 1: all-reduce of the histogram increments, UpdateDists on the sum, this rank's sample"""
-        nonlocal live_t, base_t
-        if world == 1:
-            return run.step(i, sample)
+    def exchange():
+        """N > 1, before every step: all-reduce of the histogram increments, UpdateDists on the sum.  A collective: every rank
+        calls it the same number of times (a rank whose sample range is one short still takes part in the last one)."""
         run.scene.live_get_dev(live_t.data_ptr())
         summed = pdist.allreduce_light_histograms(live_t, base_t, world, dist)
         torch.cuda.current_stream().synchronize()            # the library copies on its own stream
         run.scene.live_set_dev(summed.data_ptr())
         run.scene.update_dists()
         run.scene.live_get_dev(base_t.data_ptr())
+
+    def step(i, sample):
+        """one step of this rank"""
+        if world == 1:
+            return run.step(i, sample)
+        exchange()
         return run.step(i, sample, update_dists=0)
 
     def sync():
@@ -477,6 +488,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(steps):
         run.add(step(i, my_samples[i]))             # sampleWeight 1/(i+1): this rank's image is the running mean of ITS samples
+    if world > 1 and strong:
+        for _ in range(steps, -(-args.total_spp // world)):     # ranges differ by at most one sample: the short ranks' last exchange
+            exchange()
     if world > 1:
         # the path's one exchange step: sum of the per-GPU mean images on rank 0 (RCCL reduce over xGMI), weighted by the
         # number of samples each rank rendered
@@ -488,7 +502,7 @@ def main():
     rays = a["extensionRays"] + a["shadowRays"] + a["otherRays"] if a else 0
     total_steps = steps
     if world > 1:
-        t = torch.tensor([dt, float(rays), float(steps)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(rays), float(steps)], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); rays_all = float(tsum[1]); total_steps = int(tsum[2])

@@ -46,6 +46,12 @@ def texel_range(rank, world, total, tile=64 * 64):
     return begin, end
 
 
+def _through_host(tensor, dist):
+    """a device tensor under the gloo backend (rehearsals of the N-process flow on a box with fewer GPUs than ranks): the
+    collective runs on a host copy"""
+    return tensor.is_cuda and dist.get_backend() == "gloo"
+
+
 def reduce_mean_image(tensor, world, dist, dst=0, weight=None, total=None):
     """the path's one exchange step: tensor holds this rank's mean image; after the call rank `dst` holds the mean over
     all ranks' samples.  Equal sample counts (weight None, or weight * world == total): SUM reduce, then / world.
@@ -54,7 +60,12 @@ def reduce_mean_image(tensor, world, dist, dst=0, weight=None, total=None):
         equal = weight is None or total is None or weight * world == total
         if not equal:
             tensor.mul_(float(weight) / float(total))
-        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if _through_host(tensor, dist):
+            host = tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            tensor.copy_(host)
+        else:
+            dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
         if equal and dist.get_rank() == dst:
             tensor.mul_(1.0 / world)
     return tensor
@@ -70,5 +81,10 @@ def allreduce_light_histograms(live, base, world, dist):
     if world <= 1:
         return live
     delta = live - base
-    dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+    if _through_host(delta, dist):
+        host = delta.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        delta.copy_(host)
+    else:
+        dist.all_reduce(delta, op=dist.ReduceOp.SUM)
     return base + delta
