@@ -348,6 +348,15 @@ int pimgpu_trace_clear(PimTrace* trace);
  * :2485-2503) + TraceFn over W*H pixels (:2514-2554), one sample per pixel, running mean. */
 int pimgpu_trace_image(PimScene* scene, PimTrace* trace, const PimCamera* camera,
     PimDofInfo* dof, const PimTraceParams* params);
+/* Pt_Trace for `sampleCount` samples at once, sample indices params->sampleIndex + 0 .. sampleCount-1 -- the caller's loop
+ * around Pt_Trace (render_system.c:306-352 calls it once per frame; BASELINE config 3 runs 64 of them), sharded by SAMPLE INDEX
+ * over the device list: in round r context i renders sample r*G + i, the whole image, into its own running mean, after the
+ * replicas' light histograms have been summed and UpdateDists has run on each ([UpdateDists] once per round); at the end the
+ * contexts' means are summed on context 0 with weights n_i / sampleCount (context order, multiply then add in fp32) and the sum
+ * is blended into the image as one sample: image = lerp(image, sum, params->sampleWeight).  One context: the same with G = 1.
+ * dof: every context advances its own copy over its frames; context 0's comes back.  Statistics: summed over all frames. */
+int pimgpu_trace_image_samples(PimScene* scene, PimTrace* trace, const PimCamera* camera,
+    PimDofInfo* dof, const PimTraceParams* params, int32_t sampleCount);
 /* copy the running-mean buffers to host float3[W*H] arrays (any may be NULL);
  * the reference's callers read PtTrace.color/albedo/normal on the host (render_system.c:306-352) */
 int pimgpu_trace_download(const PimTrace* trace, float* color, float* albedo, float* normal);

@@ -113,7 +113,7 @@ EXPORTS = [
     "pimgpu_scene_create", "pimgpu_scene_destroy", "pimgpu_scene_rebuild_bvh", "pimgpu_scene_update_dists",
     "pimgpu_scene_info", "pimgpu_scene_download_lights", "pimgpu_scene_live_get_dev", "pimgpu_scene_live_set_dev",
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
-    "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image",
+    "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image", "pimgpu_trace_image_samples",
     "pimgpu_trace_download", "pimgpu_trace_image_host", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
     "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
@@ -331,6 +331,11 @@ class Trace:
 
     def trace(self, scene, camera, dof, params):
         check(self.lib.pimgpu_trace_image(scene.handle, self.handle, C.byref(camera), C.byref(dof), C.byref(params)), "pimgpu_trace_image")
+
+    def trace_samples(self, scene, camera, dof, params, count):
+        """`count` samples (indices params.sampleIndex ...) sharded by sample index over the device list, blended in as one"""
+        check(self.lib.pimgpu_trace_image_samples(scene.handle, self.handle, C.byref(camera), C.byref(dof), C.byref(params), C.c_int32(count)),
+              "pimgpu_trace_image_samples")
 
     def trace_to_host(self, scene, camera, dof, params, color, albedo=None, normal=None):
         """pimgpu_trace_image_host: the sample and the copy of the images to the host arrays (float32 [W*H, 3]) in one call"""

@@ -1407,6 +1407,8 @@ int pimgpu_trace_destroy(PimTrace* t)
             PimTrace* peer = t->peers[i]; t->peers[i] = nullptr;
             if (i < g_libCount) { DeviceScope scope(i); pimgpu_trace_destroy(peer); }
         }
+    if (t->sampleAcc) { pimgpu_trace_destroy(t->sampleAcc); t->sampleAcc = nullptr; }
+    if (t->sampleStage) { pimgpu_trace_destroy(t->sampleStage); t->sampleStage = nullptr; }
     if (g_lib.initialised) hipStreamSynchronize(g_lib.stream);
     hipFree(t->color); hipFree(t->albedo); hipFree(t->normal);
     delete t;
@@ -1585,6 +1587,158 @@ int pimgpu_trace_image(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDo
     }
     t->stats = sum;
     t->gathered = false;
+    return PIMGPU_OK;
+}
+
+/* ---- sample-index sharding over the device list ---- */
+
+static int trace_gather(const PimTrace* t);
+
+__global__ __launch_bounds__(256) void k_mean_scale(float* __restrict__ acc, int64_t n, float w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] * w;
+}
+__global__ __launch_bounds__(256) void k_mean_add(float* __restrict__ acc, const float* __restrict__ x, int64_t n, float w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] + x[i] * w;
+}
+__global__ __launch_bounds__(256) void k_mean_blend(float* __restrict__ image, const float* __restrict__ mean, int64_t n, float w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) image[i] = f1_lerp(image[i], mean[i], w);
+}
+
+/* a PimTrace of this context alone (no copies on the other contexts) */
+static int trace_create_local(int32_t width, int32_t height, PimTrace** out)
+{
+    const bool was = g_makingPeer;
+    g_makingPeer = true;
+    const int rc = pimgpu_trace_create(width, height, out);
+    g_makingPeer = was;
+    return rc;
+}
+
+static void stats_add(PimTraceStats& sum, const PimTraceStats& a)
+{
+    sum.extensionRays += a.extensionRays; sum.shadowRays += a.shadowRays; sum.otherRays += a.otherRays;
+    sum.paths += a.paths; sum.tailRays += a.tailRays; sum.wavefrontPathBounces += a.wavefrontPathBounces; sum.tailPaths += a.tailPaths;
+    sum.tailPathBounces += a.tailPathBounces; sum.traceLaunches += a.traceLaunches;
+    sum.bounces = std::max(sum.bounces, a.bounces);
+}
+
+/*
+ * BASELINE config 3's sharding ("64 spp, sharded by sample index") inside one process.  pimgpu_trace_image cuts ONE sample's
+ * pixels into bands of rows; here whole samples go to the contexts: in round r context i renders sample r*G + i of the S asked
+ * for, the whole image, into its own running mean (weight 1 / (r + 1)), after the replicas' light histograms have been summed
+ * and UpdateDists has run on every replica (scene_update_dists_all) -- the schedule bench.py's ranks follow, so each context's
+ * mean equals the image of a process that renders those samples with the same distributions, bit for bit.  Then ONE exchange
+ * step: the means travel to context 0 (device-to-device copies over xGMI) and are summed there in context order with weights
+ * n_i / S (n_i samples on context i), acc = mean_0 * w_0, acc = acc + mean_i * w_i, and the sum is blended into the PtTrace image
+ * as Pt_Trace blends a sample: image = lerp(image, acc, sampleWeight).  Every context's band of rows is refreshed from the result,
+ * so calls of pimgpu_trace_image may follow.  The autofocus state runs per context (every context sees its own samples' frames);
+ * the caller gets context 0's.  Plain peer copies and one kernel per image, not RCCL: the contexts live in one process, and a device
+ * may appear twice in the list.
+ */
+int pimgpu_trace_image_samples(PimScene* scene, PimTrace* t, const PimCamera* cam, PimDofInfo* dof, const PimTraceParams* p, int32_t sampleCount)
+{
+    int rc = check_ready(); if (rc) return rc;
+    if (!scene || !t || !cam || !dof || !p) { set_error("trace_image_samples: NULL argument"); return PIMGPU_E_INVALID; }
+    if (dof->bladeCount <= 0) { set_error("trace_image_samples: dof.bladeCount must be positive"); return PIMGPU_E_INVALID; }
+    if (sampleCount <= 0 || sampleCount > (1 << 20)) { set_error("trace_image_samples: sampleCount %d out of range", sampleCount); return PIMGPU_E_INVALID; }
+    const int G = (g_libCount > 1 && scene->peers[1] && t->peers[1]) ? g_libCount : 1;
+    const int32_t W = t->width, H = t->height;
+    const int64_t len = (int64_t)W * H * 3;
+    const size_t bytes = sizeof(float) * (size_t)len;
+    auto of = [&](int i) { return i == 0 ? t : t->peers[i]; };
+
+    rc = for_each_context(G, [&](int i) {
+        PimTrace* ti = of(i);
+        int r = PIMGPU_OK;
+        if (!ti->sampleAcc) r = trace_create_local(W, H, &ti->sampleAcc);
+        if (!r && i == 0 && G > 1 && !ti->sampleStage) r = trace_create_local(W, H, &ti->sampleStage);
+        if (r) return r;
+        /* a running mean starts from zero: 0 + (sample - 0) * 1 is the sample exactly */
+        PT_HIP(hipMemsetAsync(ti->sampleAcc->color, 0, bytes, g_lib.stream));
+        PT_HIP(hipMemsetAsync(ti->sampleAcc->albedo, 0, bytes, g_lib.stream));
+        PT_HIP(hipMemsetAsync(ti->sampleAcc->normal, 0, bytes, g_lib.stream));
+        return PIMGPU_OK;
+    });
+    if (rc) return rc;
+
+    PimDofInfo dofs[kMaxDevices];
+    PimTraceStats per[kMaxDevices];
+    for (int i = 0; i < G; ++i) { dofs[i] = *dof; memset(&per[i], 0, sizeof(per[i])); }
+    PimTraceStats total; memset(&total, 0, sizeof(total));
+    const int rounds = (sampleCount + G - 1) / G;
+    for (int r = 0; r < rounds; ++r)
+    {
+        if (G > 1 && p->updateDists) { if ((rc = scene_update_dists_all(scene))) return rc; }
+        PimTraceStats round[kMaxDevices];
+        for (int i = 0; i < G; ++i) memset(&round[i], 0, sizeof(round[i]));
+        rc = for_each_context(G, [&](int i) {
+            const int k = r * G + i;
+            if (k >= sampleCount) return PIMGPU_OK;
+            PimTraceParams q = *p;
+            q.sampleIndex = p->sampleIndex + (uint32_t)k;
+            q.sampleWeight = 1.0f / (float)(r + 1);
+            PimTrace* acc = of(i)->sampleAcc;
+            const int r2 = trace_image_one(i == 0 ? scene : scene->peers[i], acc, cam, &dofs[i], &q, 0, W * H, nullptr, nullptr, nullptr, G > 1);
+            if (!r2) round[i] = acc->stats;
+            return r2;
+        });
+        if (rc) return rc;
+        float traceMs = 0.0f, totalMs = 0.0f, aMs = 0.0f, bMs = 0.0f, tailMs = 0.0f;
+        for (int i = 0; i < G; ++i)
+        {
+            stats_add(total, round[i]);
+            /* device times: the slowest context is the round */
+            traceMs = std::max(traceMs, round[i].traceMs); totalMs = std::max(totalMs, round[i].totalMs);
+            aMs = std::max(aMs, round[i].shadeAMs); bMs = std::max(bMs, round[i].shadeBMs); tailMs = std::max(tailMs, round[i].tailMs);
+        }
+        total.traceMs += traceMs; total.totalMs += totalMs; total.shadeAMs += aMs; total.shadeBMs += bMs; total.tailMs += tailMs;
+    }
+
+    /* the exchange step, on context 0 (the caller's thread is on context 0's device: for_each_context's threads have ended);
+     * the image it blends into is whole there first (after pimgpu_trace_image every context holds its own band only) */
+    if ((rc = trace_gather(t))) return rc;
+    {
+        hipStream_t s0 = g_lib.stream;
+        const unsigned grid = (unsigned)((len + 255) / 256);
+        PimTrace* acc = t->sampleAcc;
+        float* sums[3] = { acc->color, acc->albedo, acc->normal };
+        float* images[3] = { t->color, t->albedo, t->normal };
+        for (int c = 0; c < 3; ++c)
+        {
+            const int32_t n0 = (sampleCount + G - 1) / G;                         /* context 0 renders one sample in every round */
+            k_mean_scale<<<grid, 256, 0, s0>>>(sums[c], len, (float)n0 / (float)sampleCount);
+            for (int i = 1; i < G; ++i)
+            {
+                const int32_t ni = (sampleCount - i + G - 1) / G;
+                if (i >= sampleCount || ni <= 0) continue;
+                const PimTrace* src = t->peers[i]->sampleAcc;
+                const float* from[3] = { src->color, src->albedo, src->normal };
+                float* stage[3] = { t->sampleStage->color, t->sampleStage->albedo, t->sampleStage->normal };
+                PT_HIP(hipMemcpyAsync(stage[c], from[c], bytes, hipMemcpyDeviceToDevice, s0));
+                k_mean_add<<<grid, 256, 0, s0>>>(sums[c], stage[c], len, (float)ni / (float)sampleCount);
+            }
+            k_mean_blend<<<grid, 256, 0, s0>>>(images[c], sums[c], len, p->sampleWeight);
+            /* every context keeps its band of rows of the image up to date (pimgpu_trace_image) */
+            for (int i = 1; i < G; ++i)
+            {
+                int32_t r0, r1; band_of(H, i, G, &r0, &r1);
+                const size_t off = (size_t)r0 * W * 3, bandBytes = sizeof(float) * 3 * (size_t)(r1 - r0) * W;
+                float* to[3] = { t->peers[i]->color, t->peers[i]->albedo, t->peers[i]->normal };
+                if (bandBytes) PT_HIP(hipMemcpyAsync(to[c] + off, images[c] + off, bandBytes, hipMemcpyDeviceToDevice, s0));
+            }
+        }
+        PT_HIP(hipGetLastError());
+        PT_HIP(hipStreamSynchronize(s0));
+    }
+    *dof = dofs[0];
+    t->stats = total;
+    t->gathered = true;
     return PIMGPU_OK;
 }
 

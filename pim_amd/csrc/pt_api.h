@@ -44,6 +44,10 @@ struct PimTrace
     PimTraceStats stats = {};
     PimTrace* peers[16] = {};            /* multi-device: context i keeps rows [H*i/G, H*(i+1)/G) of ITS copy up to date */
     bool gathered = true;                /* multi-device: the copy of context 0 holds every band (stddev / buffers gather on demand) */
+    /* pimgpu_trace_image_samples: this context's running mean of ITS samples (made on first use; every context's copy has its own),
+     * and on context 0 the landing place of the other contexts' means on their way into the sum */
+    PimTrace* sampleAcc = nullptr;
+    PimTrace* sampleStage = nullptr;
 };
 
 namespace pt {

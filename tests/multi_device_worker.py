@@ -61,6 +61,51 @@ def main(n):
     t.trace(g, cam, dg, scenes.trace_params(4, seed=17, max_bounces=5)); o.trace_image(img, W, H, cam, do, scenes.trace_params(4, seed=17, max_bounces=5))
     assert_bits_equal(t.download()[0], img[0], "color after raygen")
 
+    stage("sample-index sharding")
+    # BASELINE config 3's sharding inside one process (pimgpu_trace_image_samples): 5 samples over n contexts, round by round;
+    # ONE oracle scene plays every context (its UpdateDists at the start of a round sees all the contexts' increments, as the
+    # summed replicas do), each context with its own running mean and its own autofocus state
+    t2 = api.Trace(W, H)
+    img2 = [np.zeros((W * H, 3), np.float32) for _ in range(3)]
+    dg2, do2 = scenes.default_dof(), scenes.default_dof()
+    first = scenes.trace_params(0, seed=29, max_bounces=5)
+    t2.trace(g, cam, dg2, first); o.trace_image(img2, W, H, cam, do2, first)          # something to blend into
+    S = 5
+    ps = scenes.trace_params(0, seed=29, max_bounces=5); ps.sampleIndex = 10; ps.sampleWeight = 0.25
+    t2.trace_samples(g, cam, dg2, ps, S)
+    acc = [[np.zeros((W * H, 3), np.float32) for _ in range(3)] for _ in range(n)]
+    dofs = [api.PimDofInfo.from_buffer_copy(do2) for _ in range(n)]
+    rays = 0
+    for r in range((S + n - 1) // n):
+        for i in range(n):
+            k = r * n + i
+            if k < S:
+                q = scenes.trace_params(0, seed=29, max_bounces=5, update_dists=1 if i == 0 else 0)
+                q.sampleIndex = 10 + k; q.sampleWeight = 1.0 / (r + 1)
+                so = o.trace_image(acc[i], W, H, cam, dofs[i], q)
+                rays += so.extensionRays + so.shadowRays + so.otherRays
+    for c in range(3):
+        counts = [(S - i + n - 1) // n for i in range(n)]
+        mean = acc[0][c] * (np.float32(counts[0]) / np.float32(S))
+        for i in range(1, n):
+            if i < S and counts[i] > 0:
+                mean = mean + acc[i][c] * (np.float32(counts[i]) / np.float32(S))
+        img2[c] = img2[c] + (mean - img2[c]) * np.float32(0.25)
+    got = t2.download()
+    for c, name in enumerate(("color", "albedo", "normal")):
+        assert_bits_equal(got[c], img2[c], "samples: " + name)
+    sg = t2.stats()
+    assert sg.extensionRays + sg.shadowRays + sg.otherRays == rays and sg.paths == S * W * H
+    assert dg2.focalLength == dofs[0].focalLength
+    # the contexts' bands were refreshed: a row-sharded frame on top of the result
+    nxt = scenes.trace_params(3, seed=29, max_bounces=5)
+    t2.trace(g, cam, dg2, nxt); o.trace_image(img2, W, H, cam, dofs[0], nxt)
+    assert_bits_equal(t2.download()[0], img2[0], "a row-sharded frame after the sample-sharded call")
+    gl, ol = g.download_lights(), o.download_lights()
+    for k in ("live", "pdf", "cdf"):
+        assert_bits_equal(gl[k], ol[k], k + " after the sample-sharded call")
+    t2.close()
+
     stage("lightmap bake")
     # lightmap bake: 64x64 tiles round-robin over the contexts; 96^2 pages = 2x2 tiles with a ragged edge
     S = 96
