@@ -16,7 +16,9 @@ Workloads (BASELINE.json configs):
 
 At N = 1 the line also carries, as sub-records ("other_workloads"), cornell_1080p, synth1m_1080p, synth20m_1080p and the
 north star's incoherent-ray microbenchmark (shuffled surface rays in one closest-hit launch) on the 1M-triangle
-tree (2^26 rays) and on the 20M-triangle tree (2^24 rays); --no-sub skips them, PIM_BENCH_SKIP_20M=1 skips the 20M pair.
+tree (2^26 rays) and on the 20M-triangle tree (2^24 rays), and the default workload with two whole frames in flight on the one
+GPU (pimgpu_trace_image_samples over the device list [0, 0], run in a child process); --no-sub skips them, PIM_BENCH_SKIP_20M=1
+skips the 20M pair.
 --plain: no counting-build frame and no sub-records (what the profiler scripts run); --microbench-only: the two
 microbenchmarks alone.
 
@@ -384,6 +386,29 @@ def incoherent_microbench(log2_rays=26, reps=4, kind="synth1m", name="incoherent
     return rec
 
 
+def frames_in_flight(workload, contexts, samples):
+    """BASELINE config 3 renders MANY samples of one image.  pimgpu_trace_image_samples shards them by sample index over the device
+    list; with THIS GPU listed `contexts` times that many whole frames are in flight on it, each on its own stream with its own work
+    buffers, and one frame's launches fill the machine while another's drain (every launch ends with its longest rays).  Same
+    parity bar (tests/test_gpu_multi_device.py plays the schedule on the oracle, bit for bit); UpdateDists runs once per round of
+    `contexts` samples instead of once per sample.  The device list is per process, so the measurement runs in a child
+    (scripts/measure_concurrent_samples.py); a sub-record, NOT the headline: the headline step is one Pt_Trace call."""
+    import subprocess
+    rec = {"workload": "%s_%d_frames_in_flight" % (workload, contexts), "contexts_on_one_gpu": contexts, "samples_per_call": samples}
+    try:
+        run = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "scripts", "measure_concurrent_samples.py"), workload, str(contexts), str(samples)],
+                             cwd=ROOT, capture_output=True, text=True, timeout=300)
+        line = [l for l in run.stdout.splitlines() if l.startswith("{")]
+        if run.returncode != 0 or not line:
+            rec["error"] = (run.stderr or run.stdout)[-400:]
+        else:
+            d = json.loads(line[-1])
+            rec.update({"value": d["Mrays_per_s"], "unit": "Mrays/s", "ms_per_step": d["ms_per_sample"], "ms_per_call": d["ms_per_call"]})
+    except Exception as e:
+        rec["error"] = repr(e)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -550,6 +575,8 @@ def main():
                     subs.append({"workload": "synth20m_1080p", "error": repr(e)})
                 if "synth20m" in _SCENES:
                     _SCENES.pop("synth20m")[2].close()
+            if args.workload == DEFAULT_WORKLOAD and not os.environ.get("PIM_BENCH_SKIP_FRAMES_IN_FLIGHT"):
+                subs.append(frames_in_flight(args.workload, 2, 8))
             try:
                 subs.append(incoherent_microbench())
             except Exception as e:                      # a sub-record must not lose the headline line
