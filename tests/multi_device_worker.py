@@ -3,6 +3,7 @@ pimgpu_init_devices with a list of N entries -- all device 0 on the one-GPU test
 image copies on one GPU, which exercises every multi-device path except the physical peer copies -- against the oracle, bit for bit.
 
     python -m tests.multi_device_worker <N>"""
+import ctypes as C
 import sys
 
 import numpy as np
@@ -70,36 +71,52 @@ def main(n):
     dg2, do2 = scenes.default_dof(), scenes.default_dof()
     first = scenes.trace_params(0, seed=29, max_bounces=5)
     t2.trace(g, cam, dg2, first); o.trace_image(img2, W, H, cam, do2, first)          # something to blend into
-    S = 5
-    ps = scenes.trace_params(0, seed=29, max_bounces=5); ps.sampleIndex = 10; ps.sampleWeight = 0.25
-    t2.trace_samples(g, cam, dg2, ps, S)
-    acc = [[np.zeros((W * H, 3), np.float32) for _ in range(3)] for _ in range(n)]
-    dofs = [api.PimDofInfo.from_buffer_copy(do2) for _ in range(n)]
-    rays = 0
-    for r in range((S + n - 1) // n):
-        for i in range(n):
-            k = r * n + i
-            if k < S:
-                q = scenes.trace_params(0, seed=29, max_bounces=5, update_dists=1 if i == 0 else 0)
-                q.sampleIndex = 10 + k; q.sampleWeight = 1.0 / (r + 1)
-                so = o.trace_image(acc[i], W, H, cam, dofs[i], q)
-                rays += so.extensionRays + so.shadowRays + so.otherRays
-    for c in range(3):
-        counts = [(S - i + n - 1) // n for i in range(n)]
-        mean = acc[0][c] * (np.float32(counts[0]) / np.float32(S))
-        for i in range(1, n):
-            if i < S and counts[i] > 0:
-                mean = mean + acc[i][c] * (np.float32(counts[i]) / np.float32(S))
-        img2[c] = img2[c] + (mean - img2[c]) * np.float32(0.25)
-    got = t2.download()
-    for c, name in enumerate(("color", "albedo", "normal")):
-        assert_bits_equal(got[c], img2[c], "samples: " + name)
-    sg = t2.stats()
-    assert sg.extensionRays + sg.shadowRays + sg.otherRays == rays and sg.paths == S * W * H
-    assert dg2.focalLength == dofs[0].focalLength
+    rays_seen = []
+
+    def samples_case(S, weight, firstIndex):
+        """one pimgpu_trace_image_samples call and the same schedule on the oracle; img2 / dg2 / do2 carry over"""
+        ps = scenes.trace_params(0, seed=29, max_bounces=5); ps.sampleIndex = firstIndex; ps.sampleWeight = weight
+        t2.trace_samples(g, cam, dg2, ps, S)
+        acc = [[np.zeros((W * H, 3), np.float32) for _ in range(3)] for _ in range(n)]
+        dofs = [api.PimDofInfo.from_buffer_copy(do2) for _ in range(n)]
+        rays = 0
+        for r in range((S + n - 1) // n):
+            for i in range(n):
+                k = r * n + i
+                if k < S:
+                    q = scenes.trace_params(0, seed=29, max_bounces=5, update_dists=1 if i == 0 else 0)
+                    q.sampleIndex = firstIndex + k; q.sampleWeight = 1.0 / (r + 1)
+                    so = o.trace_image(acc[i], W, H, cam, dofs[i], q)
+                    rays += so.extensionRays + so.shadowRays + so.otherRays
+        counts = [(S - i + n - 1) // n if i < S else 0 for i in range(n)]
+        assert sum(counts) == S
+        for c in range(3):
+            mean = acc[0][c] * (np.float32(counts[0]) / np.float32(S))
+            for i in range(1, n):
+                if counts[i] > 0:
+                    mean = mean + acc[i][c] * (np.float32(counts[i]) / np.float32(S))
+            img2[c] = img2[c] + (mean - img2[c]) * np.float32(weight)
+        got = t2.download()
+        for c, name in enumerate(("color", "albedo", "normal")):
+            assert_bits_equal(got[c], img2[c], f"{S} samples: " + name)
+        sg = t2.stats()
+        assert sg.extensionRays + sg.shadowRays + sg.otherRays == rays and sg.paths == S * W * H
+        assert dg2.focalLength == dofs[0].focalLength
+        C.memmove(C.byref(do2), C.byref(dofs[0]), C.sizeof(do2))
+        rays_seen.append(rays)
+
+    samples_case(5, 0.25, 10)
+    samples_case(max(1, n - 1), 0.5, 40)                 # fewer samples than contexts: the last context sits the call out
+    samples_case(2 * n, 1.0, 50)                         # weight 1: the image becomes old + (mean - old), as Pt_Trace's lerp gives it
+    assert all(r > 0 for r in rays_seen)
+    try:
+        t2.trace_samples(g, cam, dg2, scenes.trace_params(0, seed=29, max_bounces=5), 0)
+        raise AssertionError("a call for 0 samples must be refused")
+    except api.PimGpuError:
+        pass
     # the contexts' bands were refreshed: a row-sharded frame on top of the result
     nxt = scenes.trace_params(3, seed=29, max_bounces=5)
-    t2.trace(g, cam, dg2, nxt); o.trace_image(img2, W, H, cam, dofs[0], nxt)
+    t2.trace(g, cam, dg2, nxt); o.trace_image(img2, W, H, cam, do2, nxt)
     assert_bits_equal(t2.download()[0], img2[0], "a row-sharded frame after the sample-sharded call")
     gl, ol = g.download_lights(), o.download_lights()
     for k in ("live", "pdf", "cdf"):
