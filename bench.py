@@ -61,6 +61,29 @@ IC_GATHER_PEAK_GBS = 8600.0       # rows gathered at random from a 38 MB table t
 # v_fma_f32 alone, 490-520 G/s on v_max3_f32 / v_cvt_f32_ubyte0 -- reported beside the spec ceiling as `attainable`.
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 VALU_ATTAINABLE_GINST = 796.6
+# ... and the opcodes fall into three issue classes there (scripts/micro/valu_classes.hip -> profiles/r03_valu_instruction_classes.txt):
+# ~3 cycles per wave64 instruction per SIMD (mov, and/or/xor, right shifts, add/sub/mul/fma f32, add/sub u32), ~4.7 (min/max, compares,
+# selects, conversions, left shifts, 3-operand integer ops, packed fp32, fp64) and ~8.9 (rcp, sqrt, ...).  scripts/valu_mix.py prices
+# each kernel's STATIC mix of loop instructions with those costs -> profiles/valu_mix.json: the rate a kernel made of these opcodes
+# can reach when its SIMDs issue VALU instructions back to back, reported as `attainable_for_mix`.
+
+
+def load_valu_mix():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def add_mix(ceiling, kernel_class):
+    """the static-mix estimate of scripts/valu_mix.py beside a kernel's measured VALU issue rate"""
+    m = load_valu_mix().get(kernel_class)
+    if m:
+        ceiling["attainable_for_mix"] = m["attainable_Ginst_per_s"]
+        ceiling["frac_of_mix_attainable"] = ceiling["achieved"] / m["attainable_Ginst_per_s"]
+        ceiling["mix"] = {"fast": m["fast_fraction"], "normal": m["normal_fraction"], "transcendental": m["transcendental_fraction"],
+                          "source": "profiles/valu_mix.json (static mix of the loop instructions; an estimate: a run whose dynamic mix is lighter can exceed it)"}
+    return ceiling
 
 WORKLOADS = {
     "synth1m_4k": dict(scene="synth1m", width=3840, height=2160, bounces=8),
@@ -228,6 +251,7 @@ class Run:
                                         "wave_insts_per_unit": pk["valu_insts_per_unit"], "lanes_per_valu_inst": pk.get("lanes_per_valu_inst"),
                                         "attainable_peak": VALU_ATTAINABLE_GINST, "frac_of_attainable": g / VALU_ATTAINABLE_GINST,
                                         "what": "VALU issue: wave64 instructions per second against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles (the fp32 vector peak); attainable = the v_fma_f32 rate measured on this pool", "source": src}
+                    add_mix(ceilings["valu"], kernel.split("<")[0])
                 if pk.get("hbm_bytes_per_unit") is not None:
                     g = units * pk["hbm_bytes_per_unit"] / sec / 1e9
                     ceilings["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
@@ -320,6 +344,7 @@ def microbench_roofline(name, n, dt, b_ray, alg, nodes, tris, worst):
         e["ceilings"]["valu"] = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
                                  "wave_insts_per_unit": pk["valu_insts_per_unit"], "lanes_per_valu_inst": pk.get("lanes_per_valu_inst"),
                                  "attainable_peak": VALU_ATTAINABLE_GINST, "frac_of_attainable": g / VALU_ATTAINABLE_GINST, "source": src}
+        add_mix(e["ceilings"]["valu"], "k_trace")
     if pk.get("hbm_bytes_per_unit") is not None:
         g = n * pk["hbm_bytes_per_unit"] / dt / 1e9
         e["ceilings"]["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "bytes_per_unit": pk["hbm_bytes_per_unit"],
