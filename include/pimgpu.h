@@ -332,6 +332,17 @@ int pimgpu_raygen(PimScene* scene, const float* origin, int32_t count,
  * Texel i = face*size^2 + y*size + x owns the stream Pcg4(i, sampleIndex, seed, k). */
 int pimgpu_cubemap_bake(PimScene* scene, float* const faces[6], int32_t size, const float* origin, float weight,
     uint32_t sampleIndex, uint32_t seed, int32_t maxBounces);
+/* Cubemap_Convolve (rendering/cubemap.c:192-303, PrefilterFn :235-262, PrefilterEnvMap :192-223; called right after Cubemap_Bake,
+ * render_system.c:239-241): every texel of every mip m of the convolved chain gets the split-sum GGX prefilter of the colour faces
+ * at roughness m / 6 (MipToRoughness, cubemap.h:66-69) from `sampleCount` samples taken in order, blended in as
+ * lerp(old, new, weight) (Cubemap_BlendMip, cubemap.h:169-188).  faces: the six host colour faces, float3[size*size]
+ * (Cubemap.color); convolved: the six host chains, float4[pimgpu_cubemap_elem_count(size)] each (Cubemap.convolved as Cubemap_New
+ * sizes it, cubemap.c:103-114: mip m at CalcMipOffset(size, m), sampler.h:42-51), read and written.  Texel i of mip m owns the
+ * stream Pcg4(m*6*size^2 + i, sampleIndex, seed, k) (the reference draws from its worker thread's generator).  The 1x1 mip is
+ * blended towards zero, as the reference's arithmetic gives it (LinearInvert divides by size - 1, sampler.h:192-195). */
+int pimgpu_cubemap_convolve(const float* const faces[6], float* const convolved[6], int32_t size, uint32_t sampleCount, float weight,
+    uint32_t sampleIndex, uint32_t seed);
+int32_t pimgpu_cubemap_elem_count(int32_t size);
 /* AmbCube_Bake (math/ambcube.c:5-32): Pt_RayGen(origin, samples) then AmbCube_Fit (ambcube.h:45-67) over the
  * samples IN ORDER with w = 6/(1+samples)/(1+prevSampleCount).  cube: AmbCube_t, 6 float4 (math/types.h:513-517),
  * host, updated in place; *newSampleCount = prevSampleCount + 1. */

@@ -7,6 +7,7 @@
  */
 #include "orc_math.h"
 #include <string.h>
+#include <stdlib.h>
 
 typedef union { float f; uint32_t u; int32_t i; } word;
 static inline float F(const uint32_t* p, int i) { word w; w.u = p[i]; return w.f; }
@@ -113,6 +114,39 @@ HOOK(lm_chartnode)
 {
     const OrcChartGeom g = ChartNodeGeom(F3(in, 0, 1.0f), F3(in, 3, 1.0f), F3(in, 6, 1.0f), F(in, 9));
     P4(out, 0, g.plane); PF(out, 4, g.a.x); PF(out, 5, g.a.y); PF(out, 6, g.b.x); PF(out, 7, g.b.y); PF(out, 8, g.c.x); PF(out, 9, g.c.y); PF(out, 10, g.area);
+}
+HOOK(Cubemap_MipChain)
+{
+    const int32_t size = (int32_t)in[0], mip = (int32_t)in[1];
+    out[0] = (uint32_t)CalcMipCount(size); out[1] = (uint32_t)CubemapElemCount(size); out[2] = (uint32_t)CalcMipOffset(size, mip);
+    out[3] = (uint32_t)CalcMipSize(size, mip < 0 ? 0 : mip);
+    PF(out, 4, MipToRoughness((float)mip)); PF(out, 5, RoughnessToMip(MipToRoughness((float)mip)));
+}
+HOOK(Cubemap_ReadColor_4)
+{
+    /* the generator's 4x4 faces (oracle/ref_golden.c): data of the record */
+    enum { CS = 4 };
+    static v3 faces[6][CS * CS];
+    const v3* color[6];
+    for (int f = 0; f < 6; ++f)
+    {
+        for (int k = 0; k < CS * CS; ++k) { faces[f][k].x = 0.25f * f + 0.0625f * k; faces[f][k].y = 1.0f / (1 + k) + f; faces[f][k].z = (float)((f * 7 + k * 3) % 11); }
+        color[f] = faces[f];
+    }
+    const v3 c = Cubemap_ReadColor(color, CS, F3(in, 0, 0.0f));
+    PF(out, 0, c.x); PF(out, 1, c.y); PF(out, 2, c.z);
+}
+HOOK(Cubemap_BlendMip)
+{
+    const int32_t size = (int32_t)in[0], face = (int32_t)in[1], mip = (int32_t)in[2], cx = (int32_t)in[3], cy = (int32_t)in[4];
+    const int32_t elems = CubemapElemCount(size);
+    v4* conv[6];
+    for (int f = 0; f < 6; ++f) { conv[f] = (v4*)malloc(sizeof(v4) * (size_t)elems); for (int k = 0; k < elems; ++k) conv[f][k] = o4_s(-7.0f); }
+    const int32_t at0 = CalcMipOffset(size, mip) + CalcMipSize(size, mip) * cy + cx;
+    conv[face][at0] = o4(F(in, 5), F(in, 6), F(in, 7), F(in, 8));
+    const int32_t at = Cubemap_BlendMip(conv, size, face, cx, cy, mip, o4(F(in, 9), F(in, 10), F(in, 11), F(in, 12)), F(in, 13));
+    out[0] = (uint32_t)face; out[1] = (uint32_t)at; P4(out, 2, conv[face][at]);
+    for (int f = 0; f < 6; ++f) free(conv[f]);
 }
 HOOK(f2_tent) { v2 r = f2_tent(o2(F(in, 0), F(in, 1))); PF(out, 0, r.x); PF(out, 1, r.y); }
 HOOK(Cubemap_CalcDir) { v4 d = Cubemap_CalcDir((int32_t)in[0], (int)in[1], (int32_t)in[2], (int32_t)in[3], o2(F(in, 4), F(in, 5))); PF(out, 0, d.x); PF(out, 1, d.y); PF(out, 2, d.z); }

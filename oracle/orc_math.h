@@ -646,6 +646,44 @@ ORC_INL int Cubemap_CalcUv(v4 dir, v2* uvOut)
     return face;
 }
 
+/* ---- the convolved mip chain of a cubemap face: rendering/sampler.h:23-51,85-88, rendering/cubemap.h:60-69,117-129,169-188 ---- */
+ORC_INL int32_t i1_log2(int32_t x)                                                               /* math/scalar.h:392-422: floor(log2 x), -1 for x <= 0 */
+{
+    int32_t y = (x > 0) ? 0 : -1;
+    if (x >= (1 << 16)) { y += 16; x >>= 16; }
+    if (x >= (1 << 8)) { y += 8; x >>= 8; }
+    if (x >= (1 << 4)) { y += 4; x >>= 4; }
+    if (x >= (1 << 2)) { y += 2; x >>= 2; }
+    if (x >= (1 << 1)) { y += 1; }
+    return y;
+}
+ORC_INL int32_t CalcMipCount(int32_t size) { return 1 + i1_log2(size); }                            /* square faces: max(size.x, size.y) = size */
+ORC_INL int32_t CalcMipSize(int32_t size, int32_t m) { int32_t y = size >> m; return y > 1 ? y : 1; }
+ORC_INL int32_t CalcMipOffset(int32_t size, int32_t m)
+{
+    const int32_t last = CalcMipCount(size) - 1;
+    m = m < 0 ? 0 : (m > last ? last : m);
+    int32_t y = 0;
+    for (int32_t i = 0; i < m; ++i) { const int32_t ms = CalcMipSize(size, i); y += ms * ms; }
+    return y;
+}
+ORC_INL int32_t CubemapElemCount(int32_t size) { return CalcMipOffset(size, CalcMipCount(size)) + 1; } /* Cubemap_New, cubemap.c:105-106 */
+#define ORC_CUBEMAP_MAX_MIP 6.0f                                                                 /* cubemap.h:12 */
+ORC_INL float RoughnessToMip(float roughness) { return roughness * ORC_CUBEMAP_MAX_MIP; }
+ORC_INL float MipToRoughness(float mip) { return mip / ORC_CUBEMAP_MAX_MIP; }
+ORC_INL v3 Cubemap_ReadColor(const v3* const color[6], int32_t size, v4 dir)
+{
+    v2 uv; const int face = Cubemap_CalcUv(dir, &uv);
+    return UvBilinearClamp_f3(color[face], size, size, uv);
+}
+/* returns the element the blend landed on */
+ORC_INL int32_t Cubemap_BlendMip(v4* const convolved[6], int32_t size, int face, int32_t cx, int32_t cy, int32_t mip, v4 value, float weight)
+{
+    const int32_t at = CalcMipOffset(size, mip) + CalcMipSize(size, mip) * cy + cx;
+    convolved[face][at] = o4_lerps(convolved[face][at], value, weight);
+    return at;
+}
+
 /* f2_tent, math/float2_funcs.h:630-636.  As written in the reference: the y lane's upper branch reads
  * Xi.x AFTER it was mapped (2 - Xi.x, not 2 - Xi.y); restated as is, the golden vectors pin it. */
 ORC_INL v2 f2_tent(v2 Xi)

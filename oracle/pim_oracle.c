@@ -1592,6 +1592,71 @@ void orc_cubemap_bake(OrcScene* s, float* const faces[6], int32_t size, const fl
     orc_parallel_for(cube_fn, &t, (int64_t)size * size * 6, threads);
 }
 
+/* Cubemap_Convolve + PrefilterFn + PrefilterEnvMap, rendering/cubemap.c:192-303: every texel of every mip of the convolved chain
+ * gets the split-sum (N = V) GGX prefilter of the colour faces at the mip's roughness, blended in with `weight`.  D1: the reference
+ * draws from the worker thread's generator (Prng_Get, cubemap.c:247), so its result depends on which thread ran which texel; here
+ * texel i of mip m owns the stream Pcg4(m * 6 * size^2 + i, sampleIndex, seed, TAG_CONV).  The sums run in sample order. */
+#define TAG_CONV     0x434F4E56u
+typedef struct { const v3* color[6]; v4* convolved[6]; int32_t size, mip, msize; uint32_t sampleCount; float weight; uint32_t sampleIndex, seed; } ConvTask;
+static v4 PrefilterEnvMap(u4* rng, const ConvTask* t, v4 N, float roughness)                     /* cubemap.c:192-223 */
+{
+    const v4 I = o4_neg(N);                                                               /* TBN.c2 = N */
+    const float alpha = BrdfAlpha(roughness);
+    float basisIntegral = 0.0f;
+    v4 lightIntegral = o4_s(0.0f);
+    for (uint32_t i = 0; i < t->sampleCount; ++i)
+    {
+        const v4 H = TanToWorld(N, SampleGGXMicrofacet(rng_f2(rng), alpha));              /* TbnToWorld(NormalToTBN(N), .) */
+        const v4 L = o4_reflect3(I, H);
+        const float NoL = o4_dot3(L, N);
+        if (NoL > 0.0f)
+        {
+            const v3 c = Cubemap_ReadColor(t->color, t->size, L);
+            v4 sample = o4(c.x, c.y, c.z, 1.0f);
+            sample = o4_muls(sample, NoL);
+            lightIntegral = o4_add(lightIntegral, sample);
+            basisIntegral += NoL;
+        }
+    }
+    if (basisIntegral > 0.0f) lightIntegral = o4_divs(lightIntegral, basisIntegral);
+    return lightIntegral;
+}
+static void conv_fn(void* user, int64_t begin, int64_t end, int tid)                            /* PrefilterFn, cubemap.c:235-262 */
+{
+    (void)tid;
+    const ConvTask* t = (const ConvTask*)user;
+    const int32_t msize = t->msize, len = msize * msize;
+    const float roughness = MipToRoughness((float)t->mip);
+    for (int64_t i = begin; i < end; ++i)
+    {
+        u4 rng = pcg4((uint32_t)((int64_t)t->mip * 6 * t->size * t->size + i), t->sampleIndex, t->seed, TAG_CONV);
+        const int32_t face = (int32_t)(i / len), fi = (int32_t)(i % len);
+        const v2 Xi = f2_tent(rng_f2(&rng));
+        const v4 N = Cubemap_CalcDir(msize, face, fi % msize, fi / msize, Xi);
+        const v4 light = PrefilterEnvMap(&rng, t, N, roughness);
+        Cubemap_BlendMip((v4* const*)t->convolved, t->size, face, fi % msize, fi / msize, t->mip, light, t->weight);
+    }
+}
+void orc_cubemap_convolve(const float* const faces[6], float* const convolved[6], int32_t size, uint32_t sampleCount, float weight,
+    uint32_t sampleIndex, uint32_t seed, int threads)
+{
+    if (size <= 0) return;
+    ConvTask t; memset(&t, 0, sizeof(t));
+    for (int f = 0; f < 6; ++f) { t.color[f] = (const v3*)faces[f]; t.convolved[f] = (v4*)convolved[f]; }
+    t.size = size; t.sampleCount = sampleCount; t.weight = weight; t.sampleIndex = sampleIndex; t.seed = seed;
+    const int32_t mipCount = CalcMipCount(size);
+    for (int32_t m = 0; m < mipCount; ++m)                                                /* cubemap.c:279-293: one task per mip */
+    {
+        const int32_t msize = size >> m;
+        const int64_t len = (int64_t)msize * msize * 6;
+        if (len <= 0) continue;
+        t.mip = m; t.msize = msize;
+        orc_parallel_for(conv_fn, &t, len, threads);
+    }
+}
+
+int32_t orc_cubemap_elem_count(int32_t size) { return size > 0 ? CubemapElemCount(size) : 0; }
+
 /* AmbCube_Bake, math/ambcube.c:5-32: Pt_RayGen + the serial fit over the samples in order */
 int32_t orc_ambcube_bake(OrcScene* s, float* cube, const float* origin, int32_t samples, int32_t prevSampleCount,
     uint32_t sampleIndex, uint32_t seed, int32_t maxBounces, int threads)

@@ -451,6 +451,68 @@ int main(int argc, char** argv)
     }
     end("GGXEnergyCompensation", N, 37, 5);
 
+    /* ---- Cubemap_Convolve's own pieces (cubemap.c:192-303, cubemap.h:60-69,117-129,169-188, sampler.h:23-51): the mip chain's
+     * layout, the roughness of a mip, the read of the colour faces and the blend into a mip texel, on a Cubemap made here
+     * (the struct is public; its faces are plain arrays) ---- */
+    begin();
+    for (int i = 0; i < 64; ++i)
+    {
+        i32 size = i < 16 ? (1 << (i % 9)) : 1 + (i32)(nextu() % 300u);
+        i32 mip = (i32)(nextu() % 12u) - 1;
+        int2 s2 = { size, size };
+        i32 mipCount = CalcMipCount(s2);
+        putu((u32)size); putu((u32)mip);
+        putu((u32)mipCount); putu((u32)(CalcMipOffset(s2, mipCount) + 1)); putu((u32)CalcMipOffset(s2, mip)); putu((u32)CalcMipSize(s2, mip < 0 ? 0 : mip).x);
+        putf(MipToRoughness((float)mip)); putf(RoughnessToMip(MipToRoughness((float)mip)));
+    }
+    end("Cubemap_MipChain", 64, 2, 6);
+    {
+        enum { CS = 4 };
+        Cubemap cm; memset(&cm, 0, sizeof(cm));
+        cm.size = CS; cm.mipCount = CalcMipCount(i2_s(CS));
+        for (int f = 0; f < 6; ++f)
+        {
+            cm.color[f] = malloc(sizeof(float3) * CS * CS);
+            for (int k = 0; k < CS * CS; ++k) cm.color[f][k] = (float3){ 0.25f * f + 0.0625f * k, 1.0f / (1 + k) + f, (float)((f * 7 + k * 3) % 11) };
+        }
+        begin();
+        for (int i = 0; i < N; ++i)
+        {
+            float4 d = rndunit(); if (i < 6) { d = f4_0; ((float*)&d)[i >> 1] = (i & 1) ? -1.0f : 1.0f; }
+            float3 c = Cubemap_ReadColor(&cm, d);
+            PUT3(d); putf(c.x); putf(c.y); putf(c.z);
+        }
+        end("Cubemap_ReadColor_4", N, 3, 3);
+        for (int f = 0; f < 6; ++f) free(cm.color[f]);
+    }
+    begin();
+    for (int i = 0; i < N; ++i)
+    {
+        i32 size = 1 << (nextu() % 7u);
+        int2 s2 = { size, size };
+        Cubemap cm; memset(&cm, 0, sizeof(cm));
+        cm.size = size; cm.mipCount = CalcMipCount(s2);
+        i32 elems = CalcMipOffset(s2, cm.mipCount) + 1;                 /* Cubemap_New, cubemap.c:105-106 */
+        i32 face = (i32)(nextu() % 6u), mip = (i32)(nextu() % (u32)cm.mipCount);
+        i32 msize = CalcMipSize(s2, mip).x;
+        int2 coord = { (i32)(nextu() % (u32)msize), (i32)(nextu() % (u32)msize) };
+        float4 old = f4_v(rnds(0, 4), rnds(0, 4), rnds(0, 4), rnds(0, 1)), val = f4_v(rnds(0, 9), rnds(0, 9), rnds(0, 9), 1.0f);
+        float weight = (i & 7) == 0 ? 1.0f : rnds(0.0f, 1.0f);
+        const float4 mark = f4_v(-7.0f, -7.0f, -7.0f, -7.0f);
+        for (int f = 0; f < 6; ++f) { cm.convolved[f] = malloc(sizeof(float4) * elems); for (int k = 0; k < elems; ++k) cm.convolved[f][k] = mark; }
+        i32 at = CalcMipOffset(s2, mip) + DecodeCoord2(CalcMipSize(s2, mip), coord);
+        cm.convolved[face][at] = old;
+        Cubemap_BlendMip(&cm, (Cubeface)face, coord, mip, val, weight);
+        i32 where = -1, touched = 0;
+        for (int f = 0; f < 6; ++f) for (int k = 0; k < elems; ++k) if (memcmp(&cm.convolved[f][k], &mark, sizeof(mark)) != 0) { where = f * elems + k; ++touched; }
+        if (touched != 1) { fprintf(stderr, "Cubemap_BlendMip touched %d texels\n", touched); return 1; }
+        float4 got = cm.convolved[where / elems][where % elems];
+        putu((u32)size); putu((u32)face); putu((u32)mip); putu((u32)coord.x); putu((u32)coord.y); PUT4(old); PUT4(val); putf(weight);
+        putu((u32)(where / elems)); putu((u32)(where % elems)); PUT4(got);
+        for (int f = 0; f < 6; ++f) free(cm.convolved[f]);
+    }
+    end("Cubemap_BlendMip", N, 14, 6);
+
     fseek(s_out, 8, SEEK_SET);
     fwrite(&s_records, 4, 1, s_out);
     fclose(s_out);

@@ -115,13 +115,34 @@ EXPORTS = [
     "pimgpu_intersect", "pimgpu_intersect_dev", "pimgpu_intersect_packed_dev", "pimgpu_trace_rays", "pimgpu_raygen",
     "pimgpu_trace_create", "pimgpu_trace_destroy", "pimgpu_trace_clear", "pimgpu_trace_image", "pimgpu_trace_image_samples",
     "pimgpu_trace_download", "pimgpu_trace_image_host", "pimgpu_trace_buffers", "pimgpu_trace_stddev", "pimgpu_trace_stats",
-    "pimgpu_cubemap_bake", "pimgpu_ambcube_bake",
+    "pimgpu_cubemap_bake", "pimgpu_cubemap_convolve", "pimgpu_cubemap_elem_count", "pimgpu_ambcube_bake",
     "pimgpu_flatten_counts", "pimgpu_flatten", "pimgpu_brdf_lut_bake", "pimgpu_lightmap_embed", "pimgpu_lightmap_chartnodes", "pimgpu_lightmap_chart_layout", "pimgpu_lightmap_chart_masks",
     "pimgpu_lightmap_bake", "pimgpu_stream", "pimgpu_work_counters", "pimgpu_trace_copy_dev", "pimgpu_trace_stddev_noalloc", "pimgpu_init_devices", "pimgpu_device_count",
     "pimgpu_lightmap_set_create", "pimgpu_lightmap_set_destroy", "pimgpu_lightmap_set_upload", "pimgpu_lightmap_set_download", "pimgpu_lightmap_set_bake", "pimgpu_lightmap_atlas_place",
 ]
 
 _LIB = None
+
+
+def cubemap_elem_count(size):
+    """float4 elements of one face's convolved mip chain (Cubemap_New, rendering/cubemap.c:103-114)"""
+    lib = load_library()
+    lib.pimgpu_cubemap_elem_count.restype = C.c_int32
+    return int(lib.pimgpu_cubemap_elem_count(C.c_int32(size)))
+
+
+def cubemap_convolve(faces, convolved, size, sample_count, weight, sampleIndex=0, seed=0):
+    """Cubemap_Convolve (rendering/cubemap.c:264-303); faces: six float32 arrays of size*size*3 (read), convolved: six float32
+    arrays of cubemap_elem_count(size)*4, blended into in place"""
+    lib = load_library()
+    elems = cubemap_elem_count(size)
+    fa, ca = (C.c_void_p * 6)(), (C.c_void_p * 6)()
+    for f in range(6):
+        assert faces[f].dtype == np.float32 and faces[f].flags["C_CONTIGUOUS"] and faces[f].size == size * size * 3
+        assert convolved[f].dtype == np.float32 and convolved[f].flags["C_CONTIGUOUS"] and convolved[f].size == elems * 4
+        fa[f] = faces[f].ctypes.data; ca[f] = convolved[f].ctypes.data
+    check(lib.pimgpu_cubemap_convolve(fa, ca, C.c_int32(size), C.c_uint32(sample_count), C.c_float(weight), C.c_uint32(sampleIndex), C.c_uint32(seed)),
+          "pimgpu_cubemap_convolve")
 
 
 class PimGpuError(RuntimeError):

@@ -780,6 +780,27 @@ PT_FN int Cubemap_CalcUv(v4 dir, v2* uvOut)
     return face;
 }
 
+/* ---- the convolved mip chain of a cubemap face: rendering/sampler.h:23-51,85-88, rendering/cubemap.h:60-69,117-129,169-188 ---- */
+PT_FN int32_t i1_log2(int32_t x) { return x > 0 ? 31 - __builtin_clz((uint32_t)x) : -1; }         /* math/scalar.h:392-422 */
+PT_FN int32_t CalcMipCount(int32_t size) { return 1 + i1_log2(size); }
+PT_FN int32_t CalcMipSize(int32_t size, int32_t m) { const int32_t y = size >> m; return y > 1 ? y : 1; }
+PT_FN int32_t CalcMipOffset(int32_t size, int32_t m)
+{
+    const int32_t last = CalcMipCount(size) - 1;
+    m = m < 0 ? 0 : (m > last ? last : m);
+    int32_t y = 0;
+    for (int32_t i = 0; i < m; ++i) { const int32_t ms = CalcMipSize(size, i); y += ms * ms; }
+    return y;
+}
+PT_FN int32_t CubemapElemCount(int32_t size) { return CalcMipOffset(size, CalcMipCount(size)) + 1; }  /* Cubemap_New, cubemap.c:105-106 */
+#define PT_CUBEMAP_MAX_MIP 6.0f                                                                  /* cubemap.h:12 */
+PT_FN float MipToRoughness(float mip) { return mip / PT_CUBEMAP_MAX_MIP; }
+PT_FN v3 Cubemap_ReadColor(const v3* const* color, int32_t size, v4 dir)
+{
+    v2 uv; const int face = Cubemap_CalcUv(dir, &uv);
+    return UvBilinearClamp_f3(color[face], size, size, uv);
+}
+
 /* f2_tent, math/float2_funcs.h:630-636.  As written in the reference: the y lane's upper branch reads
  * Xi.x AFTER it was mapped (2 - Xi.x, not 2 - Xi.y); kept, the reference's golden vectors pin it. */
 PT_FN v2 f2_tent(v2 Xi)

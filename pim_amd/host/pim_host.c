@@ -374,6 +374,39 @@ void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight)
         ms_counters.cubemap++;
 }
 
+/* Cubemap_New / Cubemap_Del, cubemap.c:96-128: size^2 colour texels and the whole mip chain of float4 per face, zeroed */
+void Cubemap_New(Cubemap* cm, i32 size)
+{
+    if (!cm) return;
+    memset(cm, 0, sizeof(*cm));
+    if (size < 0) return;
+    const i32 elems = pimgpu_cubemap_elem_count(size);
+    cm->size = size;
+    for (cm->mipCount = 0; (size >> cm->mipCount) > 0; ++cm->mipCount) { }            /* 1 + floor(log2 size), sampler.h:23-26 */
+    for (int f = 0; f < 6; ++f)
+    {
+        cm->color[f] = calloc((size_t)size * (size_t)size + 1, sizeof(float3));
+        cm->convolved[f] = calloc((size_t)elems + 1, sizeof(float4));
+    }
+}
+
+void Cubemap_Del(Cubemap* cm)
+{
+    if (!cm) return;
+    for (int f = 0; f < 6; ++f) { free(cm->color[f]); free(cm->convolved[f]); }
+    memset(cm, 0, sizeof(*cm));
+}
+
+/* Cubemap_Convolve, cubemap.c:264-303: call k of the process is sample index k of the convolution streams */
+void Cubemap_Convolve(Cubemap* cm, u32 sampleCount, float weight)
+{
+    if (!cm || cm->size <= 0) return;
+    const float* faces[6]; float* conv[6];
+    for (int f = 0; f < 6; ++f) { faces[f] = &cm->color[f]->x; conv[f] = &cm->convolved[f]->x; }
+    if (ok(pimgpu_cubemap_convolve(faces, conv, cm->size, sampleCount, weight, ms_counters.convolve, ms_config.seed), "Cubemap_Convolve"))
+        ms_counters.convolve++;
+}
+
 i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount)
 {
     i32 count = prevSampleCount;

@@ -122,7 +122,10 @@ bool LmPack_Load(Crate* crate, LmPack* dst);
 /* rendering/cubemap.h:28-34,209-213 and math/types.h:513-517, math/ambcube.h:69-74 */
 typedef struct Cubemap_s { i32 size; i32 mipCount; float3* color[6]; float4* convolved[6]; } Cubemap;
 typedef struct AmbCube_s { float4 Values[6]; } AmbCube_t;
+void Cubemap_New(Cubemap* cm, i32 size);                                    /* cubemap.c:96-115 */
+void Cubemap_Del(Cubemap* cm);                                              /* cubemap.c:117-128 */
 void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight);
+void Cubemap_Convolve(Cubemap* cm, u32 sampleCount, float weight);          /* cubemap.c:264-303 */
 i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount);
 
 /* math/lighting.h:45-55, math/types.h:503-509; BrdfLut_New / BrdfLut_Update / BrdfLut_Del, math/lighting.c:86-118 */
@@ -155,7 +158,7 @@ typedef struct PtSysConfig
 void PtSys_Configure(const PtSysConfig* config);         /* before or after PtSys_Init; also resets the call counters below */
 /* the counters that stand in for the reference's ever-advancing per-thread streams: index of the next Pt_Trace sample,
  * Pt_TraceRay stream, Pt_RayGen / AmbCube_Bake batch, Cubemap_Bake pass, LmPack_Bake pass */
-typedef struct PtSysCounters { uint32_t trace, traceRay, rayGen, cubemap, lmBake; } PtSysCounters;
+typedef struct PtSysCounters { uint32_t trace, traceRay, rayGen, cubemap, lmBake, convolve; } PtSysCounters;
 void PtSys_GetCounters(PtSysCounters* out);
 void PtTrace_DownloadAovs(PtTrace* trace);               /* with downloadAovs == 0: bring albedo / normal up to date now */
 

@@ -65,7 +65,10 @@ void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp);
 
 typedef struct Cubemap_s { i32 size; i32 mipCount; float3* color[6]; float4* convolved[6]; } Cubemap;
 typedef struct AmbCube_s { float4 Values[6]; } AmbCube_t;
+void Cubemap_New(Cubemap* cm, i32 size);
+void Cubemap_Del(Cubemap* cm);
 void Cubemap_Bake(Cubemap* cm, PtScene* scene, float4 origin, float weight);
+void Cubemap_Convolve(Cubemap* cm, u32 sampleCount, float weight);
 i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i32 prevSampleCount);
 
 /* ---- block 2: the adapter (what INTEGRATION.md adds to a Pim build) ------------------------------------------------- */
@@ -173,11 +176,17 @@ int main(int argc, char** argv)
     PtSys_Update();
 
     /* Cubemap_Bake (cubemap.c:162-190) and AmbCube_Bake (ambcube.c:5-32) */
-    Cubemap cm; memset(&cm, 0, sizeof(cm));
-    cm.size = 8;
-    for (int f = 0; f < 6; ++f) cm.color[f] = calloc(64, sizeof(float3));
+    Cubemap cm;
+    Cubemap_New(&cm, 8);
     Cubemap_Bake(&cm, scene, origin, 1.0f);
     for (int f = 0; f < 6; ++f) put(out, cm.color[f], 64 * 12);
+    /* ... and the convolution that follows it (render_system.c:239-241), twice: the second call blends into the first's result */
+    Cubemap_Convolve(&cm, 64, 1.0f);
+    Cubemap_Convolve(&cm, 64, 0.5f);
+    const i32 mips = cm.mipCount;
+    put(out, &mips, 4);
+    for (int f = 0; f < 6; ++f) put(out, cm.convolved[f], (64 + 16 + 4 + 1) * 16);
+    Cubemap_Del(&cm);
     AmbCube_t cube; memset(&cube, 0, sizeof(cube));
     i32 n = AmbCube_Bake(scene, &cube, origin, 200, 0);
     put(out, &cube, sizeof(cube)); put(out, &n, 4);

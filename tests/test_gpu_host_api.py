@@ -111,6 +111,13 @@ def test_reference_caller_gets_the_oracles_bits(tmp_path, devices):
     o.cubemap_bake(fo, 8, origin, 1.0, sampleIndex=0, seed=seed, maxBounces=mb)
     for f in range(6):
         assert_bits_equal(take(64 * 3), fo[f], f"Cubemap_Bake face {f}")
+    from tests.util import oracle_cubemap_convolve
+    conv = [np.zeros(85 * 4, np.float32) for _ in range(6)]
+    oracle_cubemap_convolve(fo, conv, 8, 64, 1.0, sampleIndex=0, seed=seed)
+    oracle_cubemap_convolve(fo, conv, 8, 64, 0.5, sampleIndex=1, seed=seed)
+    assert take(1, np.int32)[0] == 4                                                             # Cubemap_New: 1 + log2(8) mips
+    for f in range(6):
+        assert_bits_equal(take(85 * 4), conv[f], f"Cubemap_Convolve face {f}")
     cube = np.zeros((6, 4), np.float32)
     n = o.ambcube_bake(cube, origin, 200, 0, sampleIndex=1, seed=seed, maxBounces=mb)               # the second Pt_RayGen batch
     assert_bits_equal(take(24).reshape(6, 4), cube, "AmbCube_Bake"); assert take(1, np.int32)[0] == n == 1

@@ -90,3 +90,73 @@ def test_raygen_runs_update_dists_first():
         assert_bits_equal(gl3[k], ol3[k], f"{k} after ambcube")
     assert (gl3["pdf"].view(np.uint32) != gl2["pdf"].view(np.uint32)).any()
     g.close()
+
+
+# ---- Cubemap_Convolve (rendering/cubemap.c:192-303): the step render_system.c:239-241 runs right after Cubemap_Bake ----
+
+def _hdr_faces(size, seed):
+    """colour faces with a few very bright texels (a sun) on a smooth gradient"""
+    rng = np.random.default_rng(seed)
+    faces = []
+    for f in range(6):
+        a = (rng.random((size * size, 3)) * 0.5 + 0.1 * f).astype(np.float32)
+        a[rng.integers(0, size * size, 3)] += np.float32(50.0)
+        faces.append(np.ascontiguousarray(a.reshape(-1)))
+    return faces
+
+
+@pytest.mark.parametrize("size,samples", [(64, 64), (16, 7), (2, 33), (1, 4), (37, 16)])
+def test_cubemap_convolve_bit_exact(size, samples):
+    """every texel of every mip (the reference's default 64 x 64 faces with 64 samples, render_system.c:241; a size that is not a
+    power of two; the 2 x 2 and 1 x 1 chains), over two progressive calls -- the second blends into the first's result"""
+    from tests.util import oracle_cubemap_convolve, oracle_cubemap_elem_count
+    gpu_init()
+    elems = api.cubemap_elem_count(size)
+    assert elems == oracle_cubemap_elem_count(size) and elems >= size * size
+    faces = _hdr_faces(size, size + samples)
+    cg = [np.full(elems * 4, 0.25, np.float32) for _ in range(6)]
+    co = [c.copy() for c in cg]
+    for s in range(2):
+        weight = 1.0 / (1.0 + s)
+        api.cubemap_convolve(faces, cg, size, samples, weight, sampleIndex=s, seed=11)
+        oracle_cubemap_convolve(faces, co, size, samples, weight, sampleIndex=s, seed=11)
+        for f in range(6):
+            assert_bits_equal(cg[f], co[f], f"convolved face {f} call {s}")
+    allc = np.concatenate(cg).reshape(-1, 4)
+    assert np.isfinite(allc).all()
+    if size >= 16:
+        top = np.concatenate([c.reshape(-1, 4)[:size * size] for c in cg])
+        assert np.abs(top[:, 3] - 1.0).max() < 1e-6 and top[:, :3].mean() > 0.1          # w = sum(NoL) * (1 / sum(NoL))
+
+
+def test_cubemap_convolve_mip0_reads_the_faces_back_and_rougher_mips_blur():
+    """properties the split sum must have: at mip 0 (roughness 0: alpha = the minimum) every sample looks along N, so the texel is
+    (almost) the bilinear read of the faces at N; a uniform environment stays uniform at every mip that has a direction"""
+    gpu_init()
+    size = 32
+    elems = api.cubemap_elem_count(size)
+    uniform = [np.full(size * size * 3, 0.75, np.float32) for _ in range(6)]
+    conv = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    api.cubemap_convolve(uniform, conv, size, 32, 1.0, sampleIndex=0, seed=5)
+    c = np.concatenate([x.reshape(-1, 4)[:elems - 1] for x in conv])           # all but the 1 x 1 mip (NaN direction there: blended to 0)
+    assert np.abs(c[:, :3] - 0.75).max() < 1e-5 and np.abs(c[:, 3] - 1.0).max() < 1e-6        # sum * (1 / sum): f4_divvs multiplies by the reciprocal
+    assert all((x.reshape(-1, 4)[elems - 1] == 0.0).all() for x in conv)
+    grad = _hdr_faces(size, 3)
+    conv = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    api.cubemap_convolve(grad, conv, size, 16, 1.0, sampleIndex=0, seed=5)
+    src = np.concatenate([g.reshape(-1, 3) for g in grad]); m0 = np.concatenate([x.reshape(-1, 4)[:size * size, :3] for x in conv])
+    assert np.median(np.abs(m0 - src)) < 0.2                                        # the jittered direction moves at most a texel
+
+
+def test_cubemap_convolve_arguments():
+    gpu_init()
+    f = [np.zeros(3, np.float32) for _ in range(6)]
+    c = [np.zeros(4, np.float32) for _ in range(6)]
+    api.cubemap_convolve([np.zeros(0, np.float32)] * 6, [np.zeros(0, np.float32)] * 6, 0, 8, 1.0)     # size 0: nothing to do
+    assert api.cubemap_elem_count(0) == 0 and api.cubemap_elem_count(1) == 1 and api.cubemap_elem_count(64) == 5461
+    api.cubemap_convolve(f, c, 1, 0, 1.0)                                            # no samples: blended towards zero
+    lib = api.load_library()
+    import ctypes as C
+    arr = (C.c_void_p * 6)()
+    assert lib.pimgpu_cubemap_convolve(arr, arr, C.c_int32(4), C.c_uint32(1), C.c_float(1.0), C.c_uint32(0), C.c_uint32(0)) == -1          # PIMGPU_E_INVALID
+    assert lib.pimgpu_cubemap_convolve(None, None, C.c_int32(4), C.c_uint32(1), C.c_float(1.0), C.c_uint32(0), C.c_uint32(0)) == -1          # PIMGPU_E_INVALID

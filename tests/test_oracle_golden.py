@@ -53,7 +53,8 @@ def test_golden_file_covers_the_survey_list():
                  "GammaDecode_rgba8", "GammaEncode_rgba8", "UnpackEmission", "Bilinear", "Xy16ToNormalTs",
                  "Cubemap_CalcUv", "Grid", "Dist1D_Bake_Sample", "Dist1D_Update", "SG_Accumulate6",
                  "GradientNoise3", "FbmGradientNoise3", "MiePhase", "camera_basis", "trs_flatten",
-                 "f2_tent", "Cubemap_CalcDir", "AmbCube_Fit", "brdf_lut_sample", "GGXEnergyCompensation", "lm_embed_fragment", "lm_chartnode"]:
+                 "f2_tent", "Cubemap_CalcDir", "AmbCube_Fit", "brdf_lut_sample", "GGXEnergyCompensation", "lm_embed_fragment", "lm_chartnode",
+                 "Cubemap_MipChain", "Cubemap_ReadColor_4", "Cubemap_BlendMip"]:
         assert need in names, need
 
 

@@ -130,3 +130,44 @@ def test_cubemap_and_ambcube_bake_on_the_oracle(cornell):
     cube = np.zeros((6, 4), np.float32)
     n = o.ambcube_bake(cube, origin, 256, 0, sampleIndex=0, seed=2, maxBounces=3)
     assert n == 1 and (cube[:, :3] > 0).all()
+
+
+def test_cubemap_convolve_on_the_oracle():
+    """Cubemap_Convolve's restatement (oracle/pim_oracle.c, rendering/cubemap.c:192-303) against an independent numpy
+    evaluation of the same split sum for a handful of texels (same streams, float64 accumulation: agreement to float
+    rounding), plus the invariants: a uniform environment stays uniform, the 1 x 1 mip is blended towards zero, threads
+    do not change a bit, weight blends."""
+    from tests.util import oracle_cubemap_convolve, oracle_cubemap_elem_count
+    size, samples = 16, 24
+    elems = oracle_cubemap_elem_count(size)
+    assert elems == 256 + 64 + 16 + 4 + 1
+    rng = np.random.default_rng(1)
+    faces = [np.ascontiguousarray(rng.random(size * size * 3).astype(np.float32)) for _ in range(6)]
+    a = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    b = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    oracle_cubemap_convolve(faces, a, size, samples, 1.0, sampleIndex=2, seed=7, threads=1)
+    oracle_cubemap_convolve(faces, b, size, samples, 1.0, sampleIndex=2, seed=7, threads=8)
+    for f in range(6):
+        assert a[f].tobytes() == b[f].tobytes()
+    A = np.stack([x.reshape(-1, 4) for x in a])
+    assert np.isfinite(A).all() and (A[:, elems - 1] == 0).all()                   # the 1 x 1 mip: NaN direction, nothing counted
+    assert np.abs(A[:, :elems - 1, 3] - 1.0).max() < 1e-6
+    lo, hi = np.concatenate(faces).min(), np.concatenate(faces).max()
+    assert (A[:, :elems - 1, :3] >= lo - 1e-6).all() and (A[:, :elems - 1, :3] <= hi + 1e-6).all()   # a weighted mean of bilinear reads
+    # rougher mips average over wider lobes: the variance over a mip's texels falls
+    var = [A[:, o:o + n, :3].var() for o, n in ((0, 256), (256, 64), (320, 16))]
+    assert var[0] > var[1] > var[2]
+    # second call with weight 0.25 blends: new = old + (conv - old) * 0.25, conv from other streams (sampleIndex 3)
+    c = [x.copy() for x in a]
+    fresh = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    oracle_cubemap_convolve(faces, c, size, samples, 0.25, sampleIndex=3, seed=7)
+    oracle_cubemap_convolve(faces, fresh, size, samples, 1.0, sampleIndex=3, seed=7)
+    for f in range(6):
+        want = a[f] + (fresh[f] - a[f]) * np.float32(0.25)
+        assert want.tobytes() == c[f].tobytes()
+    # uniform environment
+    uni = [np.full(size * size * 3, 0.5, np.float32) for _ in range(6)]
+    u = [np.zeros(elems * 4, np.float32) for _ in range(6)]
+    oracle_cubemap_convolve(uni, u, size, samples, 1.0, seed=1)
+    U = np.stack([x.reshape(-1, 4) for x in u])[:, :elems - 1, :3]
+    assert np.abs(U - 0.5).max() < 1e-6

@@ -186,3 +186,19 @@ def brute_positions(positions, ro, rd, tNear=None, tFar=None, want_f64=False, th
     lib.orc_brute_positions(_p(positions), C.c_int32(positions.shape[0]), _p(ro), _p(rd), _p(tn), _p(tf), C.c_int32(n),
                             _p(prim), _p(tuv), _p(prim64), _p(t64), C.c_int(threads))
     return (prim, tuv, prim64, t64) if want_f64 else (prim, tuv)
+
+
+def oracle_cubemap_elem_count(size):
+    lib = load_oracle(True)
+    lib.orc_cubemap_elem_count.restype = C.c_int32
+    return int(lib.orc_cubemap_elem_count(C.c_int32(size)))
+
+
+def oracle_cubemap_convolve(faces, convolved, size, sample_count, weight, sampleIndex=0, seed=0, threads=8):
+    """Cubemap_Convolve on the oracle (oracle/pim_oracle.c: orc_cubemap_convolve); convolved is blended into in place"""
+    lib = load_oracle(True)
+    fa, ca = (C.c_void_p * 6)(), (C.c_void_p * 6)()
+    for f in range(6):
+        fa[f] = faces[f].ctypes.data; ca[f] = convolved[f].ctypes.data
+    lib.orc_cubemap_convolve.restype = None
+    lib.orc_cubemap_convolve(fa, ca, C.c_int32(size), C.c_uint32(sample_count), C.c_float(weight), C.c_uint32(sampleIndex), C.c_uint32(seed), C.c_int(threads))
