@@ -363,7 +363,7 @@ static constexpr int kPlocRadius = PT_PLOC_RADIUS;
 #define PT_PLOC_THREADS 1024
 #endif
 static constexpr int kPlocThreads = PT_PLOC_THREADS;
-static constexpr int kPlocFinish = 256;             /* at most this many clusters: one workgroup finishes in LDS */
+static constexpr int kPlocFinish = 512;             /* at most this many clusters: one workgroup finishes in LDS (37 KB) */
 
 struct PlocState { int32_t m, mPrev, nodeCounter, rootId; };
 
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter(int32_t n, const 
             hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
             id = ids + (int32_t)__popcll(mm & lt);
             child0[id] = a; child1[id] = b;
-            parent[a] = id; parent[b] = id;
+            if (parent) { parent[a] = id; parent[b] = id; }      /* only the leaf-order walks of k_ploc_order read it */
             nodeLo[id] = lo; nodeHi[id] = hi;
             count[id] = ploc_count_of(a, n, count) + ploc_count_of(b, n, count);
         }
@@ -590,16 +590,21 @@ __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish(int32_t n, PlocStat
                 count[id] = ploc_count_of(a, n, count) + ploc_count_of(b, n, count);
             }
         }
-        sPos[t] = kept ? 1 : 0;
-        __syncthreads();
-        if (t == 0)
+        /* survivors keep their order: a ballot per wave, the waves' counts summed by everyone */
         {
-            int32_t run = 0;
-            for (int i = 0; i < m; ++i) { const int32_t v = sPos[i]; sPos[i] = run; run += v; }
-            sM = run;
+            const uint64_t km = __ballot(kept);
+            const int lane = t & 63, wave = t >> 6;
+            if (lane == 0) sPos[wave] = (int32_t)__popcll(km);
+            __syncthreads();
+            int32_t before = 0, all = 0;
+            for (int w = 0; w < kPlocFinish / 64; ++w) { const int32_t v = sPos[w]; if (w < wave) before += v; all += v; }
+            if (t == 0) sM = all;
+            if (kept)
+            {
+                const int32_t dst = before + (int32_t)__popcll(km & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                sId[cur ^ 1][dst] = id; sLo[cur ^ 1][dst] = lo; sHi[cur ^ 1][dst] = hi;
+            }
         }
-        __syncthreads();
-        if (kept) { const int32_t dst = sPos[t]; sId[cur ^ 1][dst] = id; sLo[cur ^ 1][dst] = lo; sHi[cur ^ 1][dst] = hi; }
         __syncthreads();
         m = sM;
         cur ^= 1;
@@ -671,10 +676,20 @@ __global__ __launch_bounds__(256) void k_ploc_remap(int32_t n, const int32_t* __
 
 struct WideSlot { float lo[3], hi[3]; int32_t child; };
 
-__device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint32_t* __restrict__ vals,
+/*
+ * ORDER = true (the PLOC tree): the place of every subtree's leaves in the order of the finished tree is handed DOWN by the
+ * collapse instead of being computed beforehand by walks towards the root (k_ploc_order + k_ploc_remap: 1.1 of 11.5 ms at 20 M
+ * triangles).  A wide node knows where its subtree's leaves start (wideFirst); opening a binary node gives its left child the same
+ * start and its right child that start plus the left child's leaf count (count[], made by the merges); a slot that becomes a leaf
+ * writes its triangles to their places in the new order (valsOut) there and then.  `vals` stays the Morton order, leaf id c is
+ * place c - (n - 1) of it.  ORDER = false (the Karras tree, whose leaves are in tree order already): ranges as before.
+ */
+
+template <bool ORDER>
+__device__ __forceinline__ void wide_slot_from(int32_t c, int32_t first, int32_t count, int32_t n, const uint32_t* __restrict__ vals,
     const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
-    const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast, WideSlot* s)
+    const int32_t* __restrict__ child0, const int32_t* __restrict__ child1, uint32_t* __restrict__ valsOut, WideSlot* s)
 {
     float4 lo, hi;
     if (c >= n - 1)
@@ -682,13 +697,25 @@ __device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint3
         const int32_t j = c - (n - 1);
         const uint32_t t = vals[j];
         lo = triLo[t]; hi = triHi[t];
-        s->child = ~((j << 3) | 0);
+        s->child = ~(((ORDER ? first : j) << 3) | 0);
+        if (ORDER) valsOut[first] = t;
     }
     else
     {
         lo = nodeLo[c]; hi = nodeHi[c];
-        const int32_t first = rangeFirst[c], count = rangeLast[c] - first + 1;
         s->child = (count <= PT_LEAF_MAX) ? ~((first << 3) | (count - 1)) : c;
+        if (ORDER && count <= PT_LEAF_MAX)
+        {
+            /* the leaf's triangles, left to right: a subtree of at most PT_LEAF_MAX leaves */
+            int32_t todo[2 * PT_LEAF_MAX]; int top = 0, pos = first;
+            todo[top++] = c;
+            while (top > 0)
+            {
+                const int32_t x = todo[--top];
+                if (x >= n - 1) valsOut[pos++] = vals[x - (n - 1)];
+                else { todo[top++] = child1[x]; todo[top++] = child0[x]; }
+            }
+        }
     }
     s->lo[0] = lo.x; s->lo[1] = lo.y; s->lo[2] = lo.z;
     s->hi[0] = hi.x; s->hi[1] = hi.y; s->hi[2] = hi.z;
@@ -702,32 +729,41 @@ __device__ __forceinline__ void wide_slot_from(int32_t c, int32_t n, const uint3
  * (tighter boxes for free).  Wide nodes are allocated level by level from one counter, so the array is
  * compact and breadth-first: node w of level L sits in [snap[L], snap[L+1]), wideSrc[w] is its binary node.
  */
-struct Cand { int32_t id; int32_t count; float area; };
+struct Cand { int32_t id; int32_t count; int32_t first; float area; };
 
-__device__ __forceinline__ Cand cand_of(int32_t c, int32_t n, const uint32_t* __restrict__ vals,
+/* ORDER: `first` comes from the parent, the leaf count from count[] (passed as rangeLast); else both from the Karras ranges */
+template <bool ORDER>
+__device__ __forceinline__ Cand cand_of(int32_t c, int32_t first, int32_t n, const uint32_t* __restrict__ vals,
     const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
     const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast)
 {
-    float4 lo, hi; Cand k; k.id = c;
-    if (c >= n - 1) { const uint32_t t = vals[c - (n - 1)]; lo = triLo[t]; hi = triHi[t]; k.count = 1; }
-    else { lo = nodeLo[c]; hi = nodeHi[c]; k.count = rangeLast[c] - rangeFirst[c] + 1; }
+    float4 lo, hi; Cand k; k.id = c; k.first = first;
+    if (c >= n - 1) { const uint32_t t = vals[c - (n - 1)]; lo = triLo[t]; hi = triHi[t]; k.count = 1; if (!ORDER) k.first = c - (n - 1); }
+    else
+    {
+        lo = nodeLo[c]; hi = nodeHi[c];
+        if (ORDER) k.count = rangeLast[c];
+        else { k.first = rangeFirst[c]; k.count = rangeLast[c] - k.first + 1; }
+    }
     const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
     k.area = dx * dy + dy * dz + dz * dx;
     return k;
 }
 
-__global__ void k_collapse_begin(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, const int32_t* rootId)
+__global__ void k_collapse_begin(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, int32_t* wideFirst, const int32_t* rootId)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = rootId ? *rootId : 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = rootId ? *rootId : 0; wideFirst[0] = 0; }
 }
 
+template <bool ORDER>
 __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_t* __restrict__ vals,
     const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
     const int32_t* __restrict__ child0, const int32_t* __restrict__ child1,
     const int32_t* __restrict__ rangeFirst, const int32_t* __restrict__ rangeLast,
-    int32_t* __restrict__ wideSrc, const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter,
+    int32_t* __restrict__ wideSrc, int32_t* __restrict__ wideFirst, uint32_t* __restrict__ valsOut,
+    const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter,
     float4* __restrict__ wide)
 {
     const int32_t begin = snap[0], end = snap[1];
@@ -738,8 +774,9 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
     if (active)
     {
         const int32_t src = wideSrc[w];
-        cd[0] = cand_of(child0[src], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
-        cd[1] = cand_of(child1[src], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+        const int32_t at = ORDER ? wideFirst[w] : 0;
+        cd[0] = cand_of<ORDER>(child0[src], at, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+        cd[1] = cand_of<ORDER>(child1[src], at + cd[0].count, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
         ns = 2;
         /* pass 0 opens inner subtrees (count > PT_LEAF_MAX), pass 1 spends leftover slots on splitting leaves */
         for (int pass = 0; pass < 2; ++pass)
@@ -753,9 +790,10 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
                     if (open && cd[k].area > bestArea) { best = k; bestArea = cd[k].area; }
                 }
                 if (best < 0) break;
-                const int32_t c = cd[best].id;
-                cd[best] = cand_of(child0[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
-                cd[ns++] = cand_of(child1[c], n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+                const int32_t c = cd[best].id, at = cd[best].first;
+                cd[best] = cand_of<ORDER>(child0[c], at, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+                cd[ns] = cand_of<ORDER>(child1[c], at + cd[best].count, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast);
+                ++ns;
             }
         }
     }
@@ -787,8 +825,8 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
             slot[k].child = PT_BVH_EMPTY;
             continue;
         }
-        wide_slot_from(cd[k].id, n, vals, triLo, triHi, nodeLo, nodeHi, rangeFirst, rangeLast, &slot[k]);
-        if (cd[k].count > PT_LEAF_MAX) { slot[k].child = next; wideSrc[next] = cd[k].id; ++next; }
+        wide_slot_from<ORDER>(cd[k].id, cd[k].first, cd[k].count, n, vals, triLo, triHi, nodeLo, nodeHi, child0, child1, valsOut, &slot[k]);
+        if (cd[k].count > PT_LEAF_MAX) { slot[k].child = next; wideSrc[next] = cd[k].id; if (ORDER) wideFirst[next] = cd[k].first; ++next; }
     }
     float4* q = wide + (size_t)w * 8;
     q[0] = make_float4(slot[0].lo[0], slot[1].lo[0], slot[2].lo[0], slot[3].lo[0]);
@@ -998,6 +1036,9 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     }
     /* an even number of passes: the result is back in the A buffers */
     const uint32_t* order = vin;                    /* triangle of each leaf position */
+    /* PLOC: the collapse hands the leaf order down (k_collapse_level<true>); PIMGPU_BVH_ORDER_WALKS=1 keeps the walks towards the root */
+    const bool orderInCollapse = bvh_use_ploc() && !getenv("PIMGPU_BVH_ORDER_WALKS");
+    int32_t* wideFirst = newPos;                    /* a wide node's first leaf place: newPos is free when the walks are not run (else unused) */
     const int32_t* rootId = nullptr;                /* device: root of the binary tree (LBVH: node 0) */
     if (!bvh_use_ploc())
     {
@@ -1020,7 +1061,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, nn, keep, blockCount, mergeCount);
             k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
             k_ploc_scatter<<<nb, kPlocThreads, 0, stream>>>(n, ploc, keep, nn, blockCount, mergeCount, cidIn, loIn, hiIn, cidOut, loOut, hiOut,
-                child0, child1, parent, nodeLo, nodeHi, count);
+                child0, child1, orderInCollapse ? nullptr : parent, nodeLo, nodeHi, count);
             std::swap(cidIn, cidOut); std::swap(loIn, loOut); std::swap(hiIn, hiOut);
             if ((rounds & 3) == 0)
             {
@@ -1032,16 +1073,19 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             }
         }
         k_ploc_finish<<<1, kPlocFinish, 0, stream>>>(n, ploc, cidIn, loIn, hiIn, child0, child1, parent, nodeLo, nodeHi, count);
-        for (int phase = 0; phase < 3; ++phase)
-            k_ploc_order<<<grid, 256, 0, stream>>>(phase, n, vin, child0, child1, parent, count, rangeFirst, rangeLast, newPos, vals2);
-        k_ploc_remap<<<grid, 256, 0, stream>>>(n, newPos, child0, child1);
-        order = vals2;
+        if (!orderInCollapse)
+        {
+            for (int phase = 0; phase < 3; ++phase)
+                k_ploc_order<<<grid, 256, 0, stream>>>(phase, n, vin, child0, child1, parent, count, rangeFirst, rangeLast, newPos, vals2);
+            k_ploc_remap<<<grid, 256, 0, stream>>>(n, newPos, child0, child1);
+            order = vals2;
+        }
         rootId = &ploc->rootId;
     }
-    k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
+    if (!orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
     /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
      * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
-    k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, rootId);
+    k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     int32_t hostSnap[kMaxWideLevels + 2];
     int level = 0;
     bool done = false;
@@ -1054,8 +1098,14 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             /* level L holds at most 4^L nodes and never more than the binary tree has inner nodes */
             int64_t most = level < 15 ? ((int64_t)1 << (2 * level)) : (int64_t)n;
             most = std::min<int64_t>(most, n);
-            k_collapse_level<<<(int)((most + 255) / 256), 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
-                rangeFirst, rangeLast, wideSrc, snap + level, nodeCounter, b->nodes);
+            if (orderInCollapse)
+                k_collapse_level<true><<<(int)((most + 255) / 256), 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
+                    nullptr, count, wideSrc, wideFirst, vals2, snap + level, nodeCounter, b->nodes);
+            else
+                k_collapse_level<false><<<(int)((most + 255) / 256), 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
+                    rangeFirst, rangeLast, wideSrc, wideFirst, nullptr, snap + level, nodeCounter, b->nodes);
+            /* (a last-block-done counter instead of this 4-byte copy: every one of the up to 78 k blocks of a deep level's launch
+             * would hit ONE address -- 31.7 instead of 10.2 ms per build) */
             if (hipMemcpyAsync(snap + level + 2, nodeCounter, 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) return PIMGPU_E_DEVICE;
         }
         if (hipMemcpyAsync(hostSnap, snap, sizeof(int32_t) * (size_t)(level + 2), hipMemcpyDeviceToHost, stream) != hipSuccess) return PIMGPU_E_DEVICE;
@@ -1065,6 +1115,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             if (hostSnap[l + 1] == hostSnap[l]) { done = true; b->depth = l; b->nodeCount = hostSnap[l]; break; }
         }
     }
+    if (orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, vals2, n, b->tris);     /* the collapse has written the triangles' order */
     k_compress_nodes<<<(b->nodeCount + 255) / 256, 256, 0, stream>>>(b->nodes, b->nodeCount, b->cnodes);
     return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
 }
