@@ -129,16 +129,20 @@ __device__ __forceinline__ uint64_t expand_bits16(uint32_t v)
 }
 
 /*
- * Morton code of the centroid.  PT_MORTON_BITS per axis: 16 (default) gives 48-bit codes = SIX 8-bit sort passes instead of the
- * eight of 21-bit axes (20 M triangles: 13.15 -> 12.5 ms per build); a cell is then extent / 65536 (1.5 mm in the 100 m scenes),
- * far below any cluster the codes have to tell apart -- PLOC only needs the order to be locally sensible, and equal codes stay in
- * input order (the sort is stable).  Nodes and triangles per ray are unchanged (38.9 / 11.5 on the incoherent benchmark).
+ * Morton code of the centroid, PT_MORTON_BITS per axis.  PLOC only needs the order to be locally sensible -- its search looks
+ * +-4 places, and equal codes stay in input order (the sort is stable) -- so the codes can be far narrower than the 63 bits an
+ * LBVH wants, and every 8 bits less is one sort pass less.  20 M triangles, build ms | nodes + triangles per incoherent ray at
+ * 1 M / at 20 M (scripts/ab_morton.sh):  21 bits (8 passes) 13.15 | 38.9 + 11.5;  16 bits (6) 9.91 | 38.9 + 11.5 / 43.8 + 18.0;
+ * 13 bits (5) 9.72 | 39.3 + 11.6 / 43.9 + 18.0;  12 bits (5) 9.65 | 39.3 + 11.6 / 42.5 + 17.4;  10 bits (4) 9.29 | 39.0 + 11.5 /
+ * 44.0 + 18.1.  Default 13: a cell of extent / 8192 (1.2 cm in the 100 m scenes) is still below the triangles of a 20 M-triangle
+ * scene, so the order inside a cell does not have to come from the input; 10 bits measure the same HERE because the synthetic
+ * scenes list an object's triangles together.
  */
 #ifndef PT_MORTON_BITS
-#define PT_MORTON_BITS 16
+#define PT_MORTON_BITS 13
 #endif
 static constexpr int kMortonKeyBits = 3 * PT_MORTON_BITS;
-static constexpr int kSortPasses = (kMortonKeyBits + 7) / 8 + (((kMortonKeyBits + 7) / 8) & 1);      /* even: the result lands in the A buffers */
+static constexpr int kSortPasses = (kMortonKeyBits + 7) / 8;      /* the build follows the buffer the last pass wrote (kin / vin), odd or even */
 
 __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     int32_t triCount, const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
@@ -729,6 +733,10 @@ __device__ __forceinline__ void wide_slot_from(int32_t c, int32_t first, int32_t
  * (tighter boxes for free).  Wide nodes are allocated level by level from one counter, so the array is
  * compact and breadth-first: node w of level L sits in [snap[L], snap[L+1]), wideSrc[w] is its binary node.
  */
+#ifndef PT_COLLAPSE_BLOCKS
+#define PT_COLLAPSE_BLOCKS 4096
+#endif
+static constexpr int kCollapseBlocks = PT_COLLAPSE_BLOCKS;      /* blocks of a collapse launch: 16 per CU, chunks of 256 nodes in turn */
 struct Cand { int32_t id; int32_t count; int32_t first; float area; };
 
 /* ORDER: `first` comes from the parent, the leaf count from count[] (passed as rangeLast); else both from the Karras ranges */
@@ -767,8 +775,13 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
     float4* __restrict__ wide)
 {
     const int32_t begin = snap[0], end = snap[1];
-    if (begin + (int32_t)(blockIdx.x * blockDim.x) >= end) return;          /* whole block beyond the level */
-    const int32_t w = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    /* The level's size is only known on the device and the host sizes the grid from a bound (4^level, at most n): at 20 M triangles
+     * a deep level's launch had 78 k blocks of which a few thousand found nodes.  So: a grid of at most kCollapseBlocks blocks, each
+     * taking chunks of 256 nodes in turn; a block with no chunk left is gone after one comparison. */
+    __shared__ int32_t sTot[4], sBase;
+    for (int32_t chunk = (int32_t)blockIdx.x; begin + chunk * (int32_t)blockDim.x < end; chunk += (int32_t)gridDim.x)
+    {
+    const int32_t w = begin + chunk * (int32_t)blockDim.x + (int32_t)threadIdx.x;
     const bool active = w < end;
     Cand cd[4]; int ns = 0;
     if (active)
@@ -802,8 +815,8 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
     for (int k = 0; k < ns; ++k) need += (cd[k].count > PT_LEAF_MAX) ? 1 : 0;
     int incl = need;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
-    __shared__ int32_t sTot[4], sBase;
     const int wave = threadIdx.x >> 6;
+    __syncthreads();                                        /* the chunk before this one has read sTot / sBase */
     if ((threadIdx.x & 63) == 63) sTot[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0)
@@ -814,7 +827,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
     __syncthreads();
     int32_t base = sBase;
     for (int k = 0; k < wave; ++k) base += sTot[k];
-    if (!active) return;
+    if (!active) continue;
     int32_t next = base + incl - need;
     WideSlot slot[4];
     for (int k = 0; k < 4; ++k)
@@ -846,6 +859,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
         maxAbs = fmaxf(fmaxf(fmaxf(fabsf(rl.x), fabsf(rl.y)), fabsf(rl.z)), fmaxf(fmaxf(fabsf(rh.x), fabsf(rh.y)), fabsf(rh.z)));
     }
     q[7] = make_float4(maxAbs, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 /* scenes of at most PT_LEAF_MAX triangles: one node, one leaf */
@@ -1034,7 +1048,6 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
-    /* an even number of passes: the result is back in the A buffers */
     const uint32_t* order = vin;                    /* triangle of each leaf position */
     /* PLOC: the collapse hands the leaf order down (k_collapse_level<true>); PIMGPU_BVH_ORDER_WALKS=1 keeps the walks towards the root */
     const bool orderInCollapse = bvh_use_ploc() && !getenv("PIMGPU_BVH_ORDER_WALKS");
@@ -1098,11 +1111,12 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             /* level L holds at most 4^L nodes and never more than the binary tree has inner nodes */
             int64_t most = level < 15 ? ((int64_t)1 << (2 * level)) : (int64_t)n;
             most = std::min<int64_t>(most, n);
+            const int collapseGrid = (int)std::min<int64_t>((most + 255) / 256, kCollapseBlocks);
             if (orderInCollapse)
-                k_collapse_level<true><<<(int)((most + 255) / 256), 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
+                k_collapse_level<true><<<collapseGrid, 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
                     nullptr, count, wideSrc, wideFirst, vals2, snap + level, nodeCounter, b->nodes);
             else
-                k_collapse_level<false><<<(int)((most + 255) / 256), 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
+                k_collapse_level<false><<<collapseGrid, 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
                     rangeFirst, rangeLast, wideSrc, wideFirst, nullptr, snap + level, nodeCounter, b->nodes);
             /* (a last-block-done counter instead of this 4-byte copy: every one of the up to 78 k blocks of a deep level's launch
              * would hit ONE address -- 31.7 instead of 10.2 ms per build) */
