@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_ploc_init(int32_t n, const uint32_t* __
 
 /* nearest neighbour by merged surface area within +-kPlocRadius; the block's boxes are staged through LDS */
 __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn(const PlocState* __restrict__ state,
-    const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t* __restrict__ nn)
+    const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t* __restrict__ nn, int32_t stride = 1)
 {
     const int32_t m = state->m;
     const int32_t base = blockIdx.x * kPlocThreads;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn(const PlocState* __res
     for (int k = threadIdx.x; k < kPlocThreads + 2 * kPlocRadius; k += kPlocThreads)
     {
         const int32_t g = base - kPlocRadius + k;
-        if (g >= 0 && g < m) { sLo[k] = cLo[g]; sHi[k] = cHi[g]; }
+        if (g >= 0 && g < m) { sLo[k] = cLo[(size_t)g * stride]; sHi[k] = cHi[(size_t)g * stride]; }      /* stride 2: interleaved records (packed round 1) */
     }
     __syncthreads();
     const int32_t i = base + (int32_t)threadIdx.x;
@@ -862,6 +862,274 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
     }
 }
 
+/* ---------------------------------------------------------------------------------------------- */
+/* PLOC + collapse on PACKED records (round 3, the default)                                          */
+/*                                                                                                    */
+/* The clustering rounds and the collapse above keep a node's box, children, leaf count and a         */
+/* cluster's id in arrays of their own: the collapse then fetches ~6 candidates per wide node from    */
+/* five arrays each, 4 to 16 bytes at random places (3.0 of 11.5 ms at 20 M triangles), and a leaf    */
+/* candidate through vals[] -> triLo / triHi, two dependent fetches.  A box is two float4 whose w      */
+/* was unused.  Here                                                                                  */
+/*   cluster     lo = (min, bits(node id))   hi = (max, bits(leaf count))                             */
+/*   binary node lo = (min, bits(child 0))   hi = (max, bits(child 1))      + count[id]               */
+/*   leaf i      the cluster record of Morton place i (id n-1+i, count 1), kept: round 1's input list  */
+/* and lo / hi of a node or leaf sit side by side in ONE array, rec[2 c], rec[2 c + 1] (leaves behind   */
+/* the inner nodes, c = n-1+i): a candidate is one 32-byte piece of one cache line, not two lines.     */
+/* so a candidate is ONE 32-byte record (+ its count), opening it needs no further fetch (the children */
+/* came with it), the merges need no gathers for counts, no id list travels through the rounds, and   */
+/* a wide node's source is stored as its two children (coalesced reads on the next level).            */
+
+__device__ __forceinline__ float4 with_w(float4 v, int32_t w) { v.w = __int_as_float(w); return v; }
+
+__global__ __launch_bounds__(256) void k_ploc_init_p(int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ triLo, const float4* __restrict__ triHi,
+    float4* __restrict__ rec, PlocState* __restrict__ state)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { state->m = n; state->mPrev = n; state->nodeCounter = 0; state->rootId = n - 1; }
+    if (i >= n) return;
+    const uint32_t t = vals[i];
+    float4* r = rec + 2 * (size_t)((n - 1) + i);
+    r[0] = with_w(triLo[t], (n - 1) + i); r[1] = with_w(triHi[t], 1);
+}
+
+__global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter_p(const PlocState* __restrict__ state, const uint8_t* __restrict__ keep,
+    const int32_t* __restrict__ nn, const int32_t* __restrict__ blockOffset, const int32_t* __restrict__ mergeOffset,
+    const float4* __restrict__ cLoIn, const float4* __restrict__ cHiIn, int32_t strideIn, float4* __restrict__ cLoOut, float4* __restrict__ cHiOut,
+    float4* __restrict__ rec, int32_t* __restrict__ count)
+{
+    const int32_t m = state->mPrev;
+    const int32_t base = blockIdx.x * kPlocThreads;
+    if (base >= m) return;
+    const int32_t i = base + (int32_t)threadIdx.x;
+    const uint8_t f = i < m ? keep[i] : 0;
+    const bool kept = (f & PLOC_KEPT) != 0, merges = (f & PLOC_MERGES) != 0;
+    __shared__ int32_t sCnt[2][kPlocThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t km = __ballot(kept), mm = __ballot(merges);
+    if (lane == 0) { sCnt[0][wave] = (int32_t)__popcll(km); sCnt[1][wave] = (int32_t)__popcll(mm); }
+    __syncthreads();
+    int32_t off = blockOffset[blockIdx.x], ids = mergeOffset[blockIdx.x];
+    for (int w = 0; w < wave; ++w) { off += sCnt[0][w]; ids += sCnt[1][w]; }
+    if (kept)
+    {
+        const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int32_t dst = off + (int32_t)__popcll(km & lt);
+        float4 lo = cLoIn[(size_t)i * strideIn], hi = cHiIn[(size_t)i * strideIn];
+        if (merges)
+        {
+            const int32_t j = nn[i];
+            const float4 blo = cLoIn[(size_t)j * strideIn], bhi = cHiIn[(size_t)j * strideIn];
+            const int32_t a = __float_as_int(lo.w), b = __float_as_int(blo.w), leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
+            const int32_t id = ids + (int32_t)__popcll(mm & lt);
+            lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), 0.0f);
+            hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
+            rec[2 * (size_t)id] = with_w(lo, a); rec[2 * (size_t)id + 1] = with_w(hi, b); count[id] = leaves;
+            lo = with_w(lo, id); hi = with_w(hi, leaves);
+        }
+        cLoOut[dst] = lo; cHiOut[dst] = hi;
+    }
+}
+
+__global__ __launch_bounds__(kPlocFinish) void k_ploc_finish_p(PlocState* __restrict__ state,
+    const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t stride,
+    float4* __restrict__ rec, int32_t* __restrict__ count)
+{
+    __shared__ float4 sLo[2][kPlocFinish], sHi[2][kPlocFinish];
+    __shared__ int32_t sNn[kPlocFinish], sPos[kPlocFinish / 64 + 1], sM;
+    const int t = threadIdx.x;
+    int32_t m = state->m;
+    if (m > kPlocFinish) return;                         /* the host only launches this once the list is short */
+    if (t < m) { sLo[0][t] = cLo[(size_t)t * stride]; sHi[0][t] = cHi[(size_t)t * stride]; }
+    __syncthreads();
+    int cur = 0;
+    while (m > 1)
+    {
+        if (t < m)
+        {
+            float best = __builtin_inff(); int32_t bestJ = -1;
+            for (int d = -kPlocRadius; d <= kPlocRadius; ++d)
+            {
+                const int32_t j = t + d;
+                if (d == 0 || j < 0 || j >= m) continue;
+                const float a = ploc_area(sLo[cur][t], sHi[cur][t], sLo[cur][j], sHi[cur][j]);
+                if (a < best) { best = a; bestJ = j; }
+            }
+            sNn[t] = bestJ;
+        }
+        __syncthreads();
+        bool kept = false;
+        float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+        if (t < m)
+        {
+            const int32_t j = sNn[t];
+            const bool mutual = j >= 0 && sNn[j] == t;
+            kept = !(mutual && j < t);
+            lo = sLo[cur][t]; hi = sHi[cur][t];
+            if (mutual && t < j)
+            {
+                const float4 blo = sLo[cur][j], bhi = sHi[cur][j];
+                const int32_t a = __float_as_int(lo.w), b = __float_as_int(blo.w), leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
+                lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), 0.0f);
+                hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
+                const int32_t id = atomicAdd(&state->nodeCounter, 1);
+                rec[2 * (size_t)id] = with_w(lo, a); rec[2 * (size_t)id + 1] = with_w(hi, b); count[id] = leaves;
+                lo = with_w(lo, id); hi = with_w(hi, leaves);
+            }
+        }
+        {
+            const uint64_t km = __ballot(kept);
+            const int lane = t & 63, wave = t >> 6;
+            if (lane == 0) sPos[wave] = (int32_t)__popcll(km);
+            __syncthreads();
+            int32_t before = 0, all = 0;
+            for (int w = 0; w < kPlocFinish / 64; ++w) { const int32_t v = sPos[w]; if (w < wave) before += v; all += v; }
+            if (t == 0) sM = all;
+            if (kept)
+            {
+                const int32_t dst = before + (int32_t)__popcll(km & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                sLo[cur ^ 1][dst] = lo; sHi[cur ^ 1][dst] = hi;
+            }
+        }
+        __syncthreads();
+        m = sM;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (t == 0) { state->rootId = __float_as_int(sLo[cur][0].w); state->m = 1; }
+}
+
+struct CandP { int32_t id, count, first, c0, c1; float lo[3], hi[3]; float area; };
+
+__device__ __forceinline__ CandP cand_p(int32_t c, int32_t first, int32_t n, const float4* __restrict__ rec, const int32_t* __restrict__ count)
+{
+    CandP k; k.id = c; k.first = first;
+    const float4 lo = rec[2 * (size_t)c], hi = rec[2 * (size_t)c + 1];
+    if (c >= n - 1) { k.count = 1; k.c0 = k.c1 = -1; }
+    else { k.count = count[c]; k.c0 = __float_as_int(lo.w); k.c1 = __float_as_int(hi.w); }
+    k.lo[0] = lo.x; k.lo[1] = lo.y; k.lo[2] = lo.z; k.hi[0] = hi.x; k.hi[1] = hi.y; k.hi[2] = hi.z;
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    k.area = dx * dy + dy * dz + dz * dx;
+    return k;
+}
+
+/* wideSrc[0]: the root of the binary tree (node 0's spare quad wants its box); a wide node's source is its two children */
+__global__ void k_collapse_begin_p(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, int32_t* wideC0, int32_t* wideC1, int32_t* wideFirst,
+    const int32_t* rootId, const float4* __restrict__ rec)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+    {
+        const int32_t root = *rootId;
+        snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = root; wideFirst[0] = 0;
+        wideC0[0] = __float_as_int(rec[2 * (size_t)root].w); wideC1[0] = __float_as_int(rec[2 * (size_t)root + 1].w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint32_t* __restrict__ vals,
+    const float4* __restrict__ rec, const int32_t* __restrict__ count,
+    const int32_t* __restrict__ wideSrc, int32_t* __restrict__ wideC0, int32_t* __restrict__ wideC1, int32_t* __restrict__ wideFirst,
+    uint32_t* __restrict__ valsOut, const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter, float4* __restrict__ wide)
+{
+    const int32_t begin = snap[0], end = snap[1];
+    __shared__ int32_t sTot[4], sBase;
+    for (int32_t chunk = (int32_t)blockIdx.x; begin + chunk * (int32_t)blockDim.x < end; chunk += (int32_t)gridDim.x)
+    {
+        const int32_t w = begin + chunk * (int32_t)blockDim.x + (int32_t)threadIdx.x;
+        const bool active = w < end;
+        CandP cd[4]; int ns = 0;
+        if (active)
+        {
+            const int32_t at = wideFirst[w];
+            cd[0] = cand_p(wideC0[w], at, n, rec, count);
+            cd[1] = cand_p(wideC1[w], at + cd[0].count, n, rec, count);
+            ns = 2;
+            /* pass 0 opens inner subtrees (count > PT_LEAF_MAX), pass 1 spends leftover slots on splitting leaves */
+            for (int pass = 0; pass < 2; ++pass)
+            {
+                while (ns < 4)
+                {
+                    int best = -1; float bestArea = -1.0f;
+                    for (int k = 0; k < ns; ++k)
+                    {
+                        const bool open = pass == 0 ? (cd[k].count > PT_LEAF_MAX) : (cd[k].count > 1);
+                        if (open && cd[k].area > bestArea) { best = k; bestArea = cd[k].area; }
+                    }
+                    if (best < 0) break;
+                    const int32_t c0 = cd[best].c0, c1 = cd[best].c1, at2 = cd[best].first;
+                    cd[best] = cand_p(c0, at2, n, rec, count);
+                    cd[ns] = cand_p(c1, at2 + cd[best].count, n, rec, count);
+                    ++ns;
+                }
+            }
+        }
+        /* allocate the wide children of the whole block with one atomic (a single counter sustains ~90 per microsecond) */
+        int need = 0;
+        for (int k = 0; k < ns; ++k) need += (cd[k].count > PT_LEAF_MAX) ? 1 : 0;
+        int incl = need;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += v; }
+        const int wave = threadIdx.x >> 6;
+        __syncthreads();                                        /* the chunk before this one has read sTot / sBase */
+        if ((threadIdx.x & 63) == 63) sTot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const int total = sTot[0] + sTot[1] + sTot[2] + sTot[3];
+            sBase = total > 0 ? atomicAdd(nodeCounter, total) : 0;
+        }
+        __syncthreads();
+        int32_t base = sBase;
+        for (int k = 0; k < wave; ++k) base += sTot[k];
+        if (!active) continue;
+        int32_t next = base + incl - need;
+        float lo[3][4], hi[3][4]; int32_t child[4];
+        for (int k = 0; k < 4; ++k)
+        {
+            if (k >= ns)
+            {
+                for (int a = 0; a < 3; ++a) { lo[a][k] = __builtin_inff(); hi[a][k] = -__builtin_inff(); }
+                child[k] = PT_BVH_EMPTY;
+                continue;
+            }
+            for (int a = 0; a < 3; ++a) { lo[a][k] = cd[k].lo[a]; hi[a][k] = cd[k].hi[a]; }
+            if (cd[k].count > PT_LEAF_MAX)
+            {
+                child[k] = next; wideC0[next] = cd[k].c0; wideC1[next] = cd[k].c1; wideFirst[next] = cd[k].first; ++next;
+            }
+            else
+            {
+                /* a leaf: its triangles go to their places in the tree order, left to right */
+                child[k] = ~((cd[k].first << 3) | (cd[k].count - 1));
+                int32_t todo[2 * PT_LEAF_MAX]; int top = 0, pos = cd[k].first;
+                todo[top++] = cd[k].id;
+                while (top > 0)
+                {
+                    const int32_t x = todo[--top];
+                    if (x >= n - 1) valsOut[pos++] = vals[x - (n - 1)];
+                    else if (x == cd[k].id) { todo[top++] = cd[k].c1; todo[top++] = cd[k].c0; }
+                    else { todo[top++] = __float_as_int(rec[2 * (size_t)x + 1].w); todo[top++] = __float_as_int(rec[2 * (size_t)x].w); }
+                }
+            }
+        }
+        float4* q = wide + (size_t)w * 8;
+        q[0] = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+        q[1] = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+        q[2] = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
+        q[3] = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
+        q[4] = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
+        q[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+        q[6] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), __int_as_float(child[2]), __int_as_float(child[3]));
+        /* node 0's spare quad: the largest |coordinate| of the scene (traverse.h pads every box by an epsilon proportional to it) */
+        float maxAbs = 0.0f;
+        if (w == 0)
+        {
+            const int32_t rootSrc = wideSrc[0];
+            const float4 rl = rec[2 * (size_t)rootSrc], rh = rec[2 * (size_t)rootSrc + 1];
+            maxAbs = fmaxf(fmaxf(fmaxf(fabsf(rl.x), fabsf(rl.y)), fabsf(rl.z)), fmaxf(fmaxf(fabsf(rh.x), fabsf(rh.y)), fabsf(rh.z)));
+        }
+        q[7] = make_float4(maxAbs, 0.0f, 0.0f, 0.0f);
+    }
+}
+
 /* scenes of at most PT_LEAF_MAX triangles: one node, one leaf */
 __global__ void k_emit_single(int32_t n, const float4* __restrict__ triLo, const float4* __restrict__ triHi, float4* __restrict__ wide)
 {
@@ -998,6 +1266,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     const size_t oCLoA = take(sizeof(float4) * cap), oCHiA = take(sizeof(float4) * cap), oCLoB = take(sizeof(float4) * cap), oCHiB = take(sizeof(float4) * cap);
     const size_t oNn = take(4 * (size_t)cap), oKeep = take((size_t)cap), oBlockCount = take(4 * (size_t)plocBlocks + 4), oMergeCount = take(4 * (size_t)plocBlocks + 4);
     const size_t oCount = take(4 * (size_t)cap), oNewPos = take(4 * (size_t)cap), oVals2 = take(4 * (size_t)cap), oPloc = take(64);
+    const size_t oRec = take(sizeof(float4) * 2 * 2 * (size_t)cap);        /* packed records: lo, hi of inner node c at [2 c], of leaf i at [2 (n-1+i)] */
     const size_t need = off;
     if (b->capacityTris < cap || b->scratchBytes < need)
     {
@@ -1024,6 +1293,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     int32_t* nn = (int32_t*)(s + oNn); uint8_t* keep = (uint8_t*)(s + oKeep); int32_t* blockCount = (int32_t*)(s + oBlockCount); int32_t* mergeCount = (int32_t*)(s + oMergeCount);
     int32_t* count = (int32_t*)(s + oCount); int32_t* newPos = (int32_t*)(s + oNewPos); uint32_t* vals2 = (uint32_t*)(s + oVals2);
     PlocState* ploc = (PlocState*)(s + oPloc);
+    float4* rec = (float4*)(s + oRec);
 
     b->triCount = n;
     b->nodeCount = 1;
@@ -1051,6 +1321,9 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     const uint32_t* order = vin;                    /* triangle of each leaf position */
     /* PLOC: the collapse hands the leaf order down (k_collapse_level<true>); PIMGPU_BVH_ORDER_WALKS=1 keeps the walks towards the root */
     const bool orderInCollapse = bvh_use_ploc() && !getenv("PIMGPU_BVH_ORDER_WALKS");
+    /* ... and runs on packed records (k_*_p); PIMGPU_BVH_PACKED=0 keeps the arrays-per-field kernels */
+    const char* packedEnv = getenv("PIMGPU_BVH_PACKED");
+    const bool packed = orderInCollapse && !(packedEnv && packedEnv[0] == '0');
     int32_t* wideFirst = newPos;                    /* a wide node's first leaf place: newPos is free when the walks are not run (else unused) */
     const int32_t* rootId = nullptr;                /* device: root of the binary tree (LBVH: node 0) */
     if (!bvh_use_ploc())
@@ -1058,6 +1331,35 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         k_karras<<<grid, 256, 0, stream>>>(kin, n, child0, child1, parent, rangeFirst, rangeLast);
         hipMemsetAsync(flags, 0, 4 * (size_t)n, stream);
         k_refit<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, child0, child1, parent, nodeLo, nodeHi, flags);
+    }
+    else if (packed)
+    {
+        k_ploc_init_p<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, rec, ploc);
+        const float4* loIn = rec + 2 * (size_t)(n - 1); const float4* hiIn = loIn + 1;           /* round 1 reads the leaves' records, which stay */
+        int32_t strideIn = 2;
+        float4* loOut = cLoA; float4* hiOut = cHiA;
+        int32_t mHost = n;
+        int rounds = 0;
+        while (mHost > kPlocFinish)
+        {
+            if (++rounds > 4096) { set_error("BVH build: clustering does not converge"); return PIMGPU_E_STATE; }
+            const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
+            k_ploc_nn<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, nn, strideIn);
+            k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, nn, keep, blockCount, mergeCount);
+            k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
+            k_ploc_scatter_p<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, nn, blockCount, mergeCount, loIn, hiIn, strideIn, loOut, hiOut, rec, count);
+            loIn = loOut; hiIn = hiOut; strideIn = 1;
+            loOut = (loOut == cLoA) ? cLoB : cLoA; hiOut = (hiOut == cHiA) ? cHiB : cHiA;
+            if ((rounds & 3) == 0)
+            {
+                PlocState hs;
+                if (hipMemcpyAsync(&hs, ploc, sizeof(hs), hipMemcpyDeviceToHost, stream) != hipSuccess) return PIMGPU_E_DEVICE;
+                if (hipStreamSynchronize(stream) != hipSuccess) return PIMGPU_E_DEVICE;
+                mHost = hs.m;
+            }
+        }
+        k_ploc_finish_p<<<1, kPlocFinish, 0, stream>>>(ploc, loIn, hiIn, strideIn, rec, count);
+        rootId = &ploc->rootId;
     }
     else
     {
@@ -1098,7 +1400,8 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     if (!orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
     /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
      * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
-    k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
+    if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, child0, child1, wideFirst, rootId, rec);
+    else k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     int32_t hostSnap[kMaxWideLevels + 2];
     int level = 0;
     bool done = false;
@@ -1112,7 +1415,10 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             int64_t most = level < 15 ? ((int64_t)1 << (2 * level)) : (int64_t)n;
             most = std::min<int64_t>(most, n);
             const int collapseGrid = (int)std::min<int64_t>((most + 255) / 256, kCollapseBlocks);
-            if (orderInCollapse)
+            if (packed)
+                k_collapse_level_p<<<collapseGrid, 256, 0, stream>>>(n, order, rec, count, wideSrc, child0, child1, wideFirst,
+                    vals2, snap + level, nodeCounter, b->nodes);
+            else if (orderInCollapse)
                 k_collapse_level<true><<<collapseGrid, 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
                     nullptr, count, wideSrc, wideFirst, vals2, snap + level, nodeCounter, b->nodes);
             else
