@@ -144,6 +144,18 @@ __device__ __forceinline__ uint64_t expand_bits16(uint32_t v)
 static constexpr int kMortonKeyBits = 3 * PT_MORTON_BITS;
 static constexpr int kSortPasses = (kMortonKeyBits + 7) / 8;      /* the build follows the buffer the last pass wrote (kin / vin), odd or even */
 
+/* kIndexBits: with at most 2^25 triangles and codes of at most 39 bits the triangle's index rides in the low bits of its key, and a
+ * sort pass moves 8 bytes per triangle instead of 12 (vals == nullptr; the passes start at bit 25, k_unpack_vals reads the order off
+ * the sorted keys).  Equal codes stay in index order either way: the sort is stable. */
+static constexpr int kIndexBits = 25;
+static constexpr bool kCanPackIndex = kMortonKeyBits + kIndexBits <= 64;
+
+__global__ __launch_bounds__(256) void k_unpack_vals(const uint64_t* __restrict__ keys, int32_t n, uint32_t* __restrict__ vals)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vals[i] = (uint32_t)(keys[i] & ((1ull << kIndexBits) - 1ull));
+}
+
 __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ triLo, const float4* __restrict__ triHi,
     int32_t triCount, const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
@@ -162,9 +174,10 @@ __global__ __launch_bounds__(256) void k_morton(const float4* __restrict__ triLo
         uint32_t v = (uint32_t)(t * (float)cells);
         q[a] = v > cells - 1u ? cells - 1u : v;
     }
-    keys[i] = PT_MORTON_BITS > 16 ? (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2])
-                                  : (expand_bits16(q[0]) << 2) | (expand_bits16(q[1]) << 1) | expand_bits16(q[2]);
-    vals[i] = (uint32_t)i;
+    const uint64_t code = PT_MORTON_BITS > 16 ? (expand_bits21(q[0]) << 2) | (expand_bits21(q[1]) << 1) | expand_bits21(q[2])
+                                              : (expand_bits16(q[0]) << 2) | (expand_bits16(q[1]) << 1) | expand_bits16(q[2]);
+    if (vals) { keys[i] = code; vals[i] = (uint32_t)i; }
+    else keys[i] = (code << kIndexBits) | (uint64_t)(uint32_t)i;
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? keysIn[i] : ~0ull;
-        val[r] = valid ? valsIn[i] : 0u;
+        val[r] = (valid && valsIn) ? valsIn[i] : 0u;
         const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
         uint64_t match = __ballot(valid);
         for (int b = 0; b < 8; ++b)
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
             const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
             const uint32_t dst = waveCnt[wave][d] + rank[r];
             keysOut[dst] = key[r];
-            valsOut[dst] = val[r];
+            if (valsIn) valsOut[dst] = val[r];
         }
     }
 }
@@ -1308,16 +1321,20 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         if (n > 0) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, nullptr, n, b->tris);
         return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;
     }
-    k_morton<<<grid, 256, 0, stream>>>(triLo, triHi, n, bounds, keysA, valsA);
+    /* PLOC: the index rides in the key (LBVH keeps separate values: k_karras reads the codes themselves) */
+    const bool packIndex = kCanPackIndex && bvh_use_ploc() && (int64_t)n <= (1ll << kIndexBits) && !getenv("PIMGPU_BVH_SORT_VALUES");
+    k_morton<<<grid, 256, 0, stream>>>(triLo, triHi, n, bounds, keysA, packIndex ? nullptr : valsA);
     uint64_t* kin = keysA; uint64_t* kout = keysB; uint32_t* vin = valsA; uint32_t* vout = valsB;
-    for (int shift = 0; shift < 8 * kSortPasses; shift += 8)
+    const int shift0 = packIndex ? kIndexBits : 0;
+    for (int shift = shift0; shift < shift0 + 8 * kSortPasses; shift += 8)
     {
         k_sort_hist<<<numBlocks, kSortThreads, 0, stream>>>(kin, n, shift, counts, numBlocks);
         k_sort_scan<<<256, 256, 0, stream>>>(counts, numBlocks, totals);
-        k_sort_scatter<<<numBlocks, kSortThreads, 0, stream>>>(kin, vin, kout, vout, n, shift, counts, totals, numBlocks);
+        k_sort_scatter<<<numBlocks, kSortThreads, 0, stream>>>(kin, packIndex ? nullptr : vin, kout, vout, n, shift, counts, totals, numBlocks);
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
+    if (packIndex) k_unpack_vals<<<grid, 256, 0, stream>>>(kin, n, vin);
     const uint32_t* order = vin;                    /* triangle of each leaf position */
     /* PLOC: the collapse hands the leaf order down (k_collapse_level<true>); PIMGPU_BVH_ORDER_WALKS=1 keeps the walks towards the root */
     const bool orderInCollapse = bvh_use_ploc() && !getenv("PIMGPU_BVH_ORDER_WALKS");
