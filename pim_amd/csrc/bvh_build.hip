@@ -473,6 +473,70 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_merge(const PlocState* __
     }
 }
 
+/*
+ * k_ploc_nn + k_ploc_merge in one launch (the packed path): a block finds the nearest neighbours of its own elements AND of the
+ * kPlocRadius elements to either side (boxes with a halo of 2 * kPlocRadius), so that "is the choice mutual" is answered from LDS;
+ * the halo's neighbours are found twice, by two blocks, with the same result.  One launch and one pass over nn[] less per round.
+ */
+__global__ __launch_bounds__(kPlocThreads) void k_ploc_nn_merge(const PlocState* __restrict__ state,
+    const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t stride, int32_t* __restrict__ nn,
+    uint8_t* __restrict__ keep, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount)
+{
+    constexpr int R = kPlocRadius, kBox = kPlocThreads + 4 * R, kNn = kPlocThreads + 2 * R;
+    const int32_t m = state->m;
+    const int32_t base = blockIdx.x * kPlocThreads;
+    if (base >= m) { if (threadIdx.x == 0) { blockCount[blockIdx.x] = 0; mergeCount[blockIdx.x] = 0; } return; }
+    __shared__ float4 sLo[kBox], sHi[kBox];
+    __shared__ int32_t sNn[kNn];
+    __shared__ int32_t sCnt[2][kPlocThreads / 64];
+    for (int k = threadIdx.x; k < kBox; k += kPlocThreads)
+    {
+        const int32_t g = base - 2 * R + k;
+        if (g >= 0 && g < m) { sLo[k] = cLo[(size_t)g * stride]; sHi[k] = cHi[(size_t)g * stride]; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kNn; k += kPlocThreads)
+    {
+        const int32_t e = base - R + k;                        /* element whose neighbour this is; its box sits at sLo[k + R] */
+        int32_t bestJ = -1;
+        if (e >= 0 && e < m)
+        {
+            const float4 lo = sLo[k + R], hi = sHi[k + R];
+            float best = __builtin_inff();
+            for (int d = -R; d <= R; ++d)
+            {
+                const int32_t j = e + d;
+                if (d == 0 || j < 0 || j >= m) continue;
+                const float a = ploc_area(lo, hi, sLo[k + R + d], sHi[k + R + d]);
+                if (a < best) { best = a; bestJ = j; }          /* ascending j: ties keep the lower index */
+            }
+        }
+        sNn[k] = bestJ;
+    }
+    __syncthreads();
+    const int32_t i = base + (int32_t)threadIdx.x;
+    bool kept = false, merges = false;
+    if (i < m)
+    {
+        const int32_t j = sNn[threadIdx.x + R];
+        const bool mutual = j >= 0 && sNn[j - base + R] == i;
+        kept = !(mutual && j < i);
+        merges = mutual && i < j;
+        nn[i] = j;
+        keep[i] = (kept ? PLOC_KEPT : 0) | (merges ? PLOC_MERGES : 0);
+    }
+    const int lane = threadIdx.x & 63;
+    const uint64_t km = __ballot(kept), mm = __ballot(merges);
+    if (lane == 0) { sCnt[0][threadIdx.x >> 6] = (int32_t)__popcll(km); sCnt[1][threadIdx.x >> 6] = (int32_t)__popcll(mm); }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int32_t t = 0, u = 0;
+        for (int w = 0; w < kPlocThreads / 64; ++w) { t += sCnt[0][w]; u += sCnt[1][w]; }
+        blockCount[blockIdx.x] = t; mergeCount[blockIdx.x] = u;
+    }
+}
+
 /* exclusive scans of the per-block survivor and merge counts (one workgroup): new list length, first node id of each block */
 static constexpr int kScanThreads = 1024;
 
@@ -1361,8 +1425,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         {
             if (++rounds > 4096) { set_error("BVH build: clustering does not converge"); return PIMGPU_E_STATE; }
             const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
-            k_ploc_nn<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, nn, strideIn);
-            k_ploc_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, nn, keep, blockCount, mergeCount);
+            k_ploc_nn_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, strideIn, nn, keep, blockCount, mergeCount);
             k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
             k_ploc_scatter_p<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, nn, blockCount, mergeCount, loIn, hiIn, strideIn, loOut, hiOut, rec, count);
             loIn = loOut; hiIn = hiOut; strideIn = 1;
