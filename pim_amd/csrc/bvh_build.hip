@@ -945,35 +945,45 @@ __global__ __launch_bounds__(256) void k_collapse_level(int32_t n, const uint32_
 /* The clustering rounds and the collapse above keep a node's box, children, leaf count and a         */
 /* cluster's id in arrays of their own: the collapse then fetches ~6 candidates per wide node from    */
 /* five arrays each, 4 to 16 bytes at random places (3.0 of 11.5 ms at 20 M triangles), and a leaf    */
-/* candidate through vals[] -> triLo / triHi, two dependent fetches.  A box is two float4 whose w      */
-/* was unused.  Here                                                                                  */
-/*   cluster     lo = (min, bits(node id))   hi = (max, bits(leaf count))                             */
-/*   binary node lo = (min, bits(child 0))   hi = (max, bits(child 1))      + count[id]               */
-/*   leaf i      the cluster record of Morton place i (id n-1+i, count 1), kept: round 1's input list  */
-/* and lo / hi of a node or leaf sit side by side in ONE array, rec[2 c], rec[2 c + 1] (leaves behind   */
-/* the inner nodes, c = n-1+i): a candidate is one 32-byte piece of one cache line, not two lines.     */
-/* so a candidate is ONE 32-byte record (+ its count), opening it needs no further fetch (the children */
-/* came with it), the merges need no gathers for counts, no id list travels through the rounds, and   */
-/* a wide node's source is stored as its two children (coalesced reads on the next level).            */
+/* candidate through vals[] -> triLo / triHi, two dependent fetches.  Here                            */
+/*   cluster      lo = (min, bits(node id))   hi = (max, bits(leaf count))   (the w of a box's two    */
+/*                float4 was unused): no id list travels through the rounds, the merges gather nothing */
+/*   binary node  ONE 64-byte line holding what the collapse wants when it OPENS the node: the boxes, */
+/*                ids and leaf counts of its two CHILDREN                                              */
+/*                  [0] = (min of child 0, bits(child 0))   [1] = (max of child 0, bits(child 1))      */
+/*                  [2] = (min of child 1, bits(count 0))   [3] = (max of child 1, bits(count 1))      */
+/* A wide node costs one line for its source and one per node it opens (at most two more) instead of  */
+/* six 32-byte candidates and six counts, and leaves need no records at all: their boxes sit in their  */
+/* parents' lines.  The collapse is bound by random lines from HBM (~2 TB/s of them), so lines count. */
 
+static constexpr int kRec = 4;
 __device__ __forceinline__ float4 with_w(float4 v, int32_t w) { v.w = __int_as_float(w); return v; }
+
+__device__ __forceinline__ void node_record(float4* __restrict__ rec, int32_t id, float4 alo, float4 ahi, float4 blo, float4 bhi)
+{
+    /* a, b: the merging clusters' records (lo.w = id, hi.w = leaf count) */
+    float4* r = rec + kRec * (size_t)id;
+    r[0] = alo;                                                 /* min 0 | child 0 */
+    r[1] = with_w(ahi, __float_as_int(blo.w));                  /* max 0 | child 1 */
+    r[2] = with_w(blo, __float_as_int(ahi.w));                  /* min 1 | count 0 */
+    r[3] = bhi;                                                 /* max 1 | count 1 */
+}
 
 __global__ __launch_bounds__(256) void k_ploc_init_p(int32_t n, const uint32_t* __restrict__ vals,
     const float4* __restrict__ triLo, const float4* __restrict__ triHi,
-    float4* __restrict__ rec, PlocState* __restrict__ state)
+    float4* __restrict__ cLo, float4* __restrict__ cHi, PlocState* __restrict__ state)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { state->m = n; state->mPrev = n; state->nodeCounter = 0; state->rootId = n - 1; }
     if (i >= n) return;
     const uint32_t t = vals[i];
-    float4* r = rec + 2 * (size_t)((n - 1) + i);
-    r[0] = with_w(triLo[t], (n - 1) + i); r[1] = with_w(triHi[t], 1);
+    cLo[i] = with_w(triLo[t], (n - 1) + i); cHi[i] = with_w(triHi[t], 1);
 }
 
 __global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter_p(const PlocState* __restrict__ state, const uint8_t* __restrict__ keep,
     const int32_t* __restrict__ nn, const int32_t* __restrict__ blockOffset, const int32_t* __restrict__ mergeOffset,
-    const float4* __restrict__ cLoIn, const float4* __restrict__ cHiIn, int32_t strideIn, float4* __restrict__ cLoOut, float4* __restrict__ cHiOut,
-    float4* __restrict__ rec, int32_t* __restrict__ count)
+    const float4* __restrict__ cLoIn, const float4* __restrict__ cHiIn, float4* __restrict__ cLoOut, float4* __restrict__ cHiOut,
+    float4* __restrict__ rec)
 {
     const int32_t m = state->mPrev;
     const int32_t base = blockIdx.x * kPlocThreads;
@@ -992,32 +1002,30 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter_p(const PlocState
     {
         const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const int32_t dst = off + (int32_t)__popcll(km & lt);
-        float4 lo = cLoIn[(size_t)i * strideIn], hi = cHiIn[(size_t)i * strideIn];
+        float4 lo = cLoIn[i], hi = cHiIn[i];
         if (merges)
         {
             const int32_t j = nn[i];
-            const float4 blo = cLoIn[(size_t)j * strideIn], bhi = cHiIn[(size_t)j * strideIn];
-            const int32_t a = __float_as_int(lo.w), b = __float_as_int(blo.w), leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
+            const float4 blo = cLoIn[j], bhi = cHiIn[j];
+            const int32_t leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
             const int32_t id = ids + (int32_t)__popcll(mm & lt);
-            lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), 0.0f);
-            hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
-            rec[2 * (size_t)id] = with_w(lo, a); rec[2 * (size_t)id + 1] = with_w(hi, b); count[id] = leaves;
-            lo = with_w(lo, id); hi = with_w(hi, leaves);
+            node_record(rec, id, lo, hi, blo, bhi);
+            lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), __int_as_float(id));
+            hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), __int_as_float(leaves));
         }
         cLoOut[dst] = lo; cHiOut[dst] = hi;
     }
 }
 
 __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish_p(PlocState* __restrict__ state,
-    const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t stride,
-    float4* __restrict__ rec, int32_t* __restrict__ count)
+    const float4* __restrict__ cLo, const float4* __restrict__ cHi, float4* __restrict__ rec)
 {
     __shared__ float4 sLo[2][kPlocFinish], sHi[2][kPlocFinish];
     __shared__ int32_t sNn[kPlocFinish], sPos[kPlocFinish / 64 + 1], sM;
     const int t = threadIdx.x;
     int32_t m = state->m;
     if (m > kPlocFinish) return;                         /* the host only launches this once the list is short */
-    if (t < m) { sLo[0][t] = cLo[(size_t)t * stride]; sHi[0][t] = cHi[(size_t)t * stride]; }
+    if (t < m) { sLo[0][t] = cLo[t]; sHi[0][t] = cHi[t]; }
     __syncthreads();
     int cur = 0;
     while (m > 1)
@@ -1046,12 +1054,11 @@ __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish_p(PlocState* __rest
             if (mutual && t < j)
             {
                 const float4 blo = sLo[cur][j], bhi = sHi[cur][j];
-                const int32_t a = __float_as_int(lo.w), b = __float_as_int(blo.w), leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
-                lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), 0.0f);
-                hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), 0.0f);
+                const int32_t leaves = __float_as_int(hi.w) + __float_as_int(bhi.w);
                 const int32_t id = atomicAdd(&state->nodeCounter, 1);
-                rec[2 * (size_t)id] = with_w(lo, a); rec[2 * (size_t)id + 1] = with_w(hi, b); count[id] = leaves;
-                lo = with_w(lo, id); hi = with_w(hi, leaves);
+                node_record(rec, id, lo, hi, blo, bhi);
+                lo = make_float4(fminf(lo.x, blo.x), fminf(lo.y, blo.y), fminf(lo.z, blo.z), __int_as_float(id));
+                hi = make_float4(fmaxf(hi.x, bhi.x), fmaxf(hi.y, bhi.y), fmaxf(hi.z, bhi.z), __int_as_float(leaves));
             }
         }
         {
@@ -1076,35 +1083,33 @@ __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish_p(PlocState* __rest
     if (t == 0) { state->rootId = __float_as_int(sLo[cur][0].w); state->m = 1; }
 }
 
-struct CandP { int32_t id, count, first, c0, c1; float lo[3], hi[3]; float area; };
+struct CandP { int32_t id, count, first; float lo[3], hi[3]; float area; };
 
-__device__ __forceinline__ CandP cand_p(int32_t c, int32_t first, int32_t n, const float4* __restrict__ rec, const int32_t* __restrict__ count)
+__device__ __forceinline__ void cand_box(CandP& k, float4 lo, float4 hi)
 {
-    CandP k; k.id = c; k.first = first;
-    const float4 lo = rec[2 * (size_t)c], hi = rec[2 * (size_t)c + 1];
-    if (c >= n - 1) { k.count = 1; k.c0 = k.c1 = -1; }
-    else { k.count = count[c]; k.c0 = __float_as_int(lo.w); k.c1 = __float_as_int(hi.w); }
     k.lo[0] = lo.x; k.lo[1] = lo.y; k.lo[2] = lo.z; k.hi[0] = hi.x; k.hi[1] = hi.y; k.hi[2] = hi.z;
     const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
     k.area = dx * dy + dy * dz + dz * dx;
-    return k;
 }
 
-/* wideSrc[0]: the root of the binary tree (node 0's spare quad wants its box); a wide node's source is its two children */
-__global__ void k_collapse_begin_p(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, int32_t* wideC0, int32_t* wideC1, int32_t* wideFirst,
-    const int32_t* rootId, const float4* __restrict__ rec)
+/* opening binary node c, whose leaves start at `first`: its two children as candidates, from its one line */
+__device__ __forceinline__ void open_node(const float4* __restrict__ rec, int32_t c, int32_t first, CandP& a, CandP& b)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-    {
-        const int32_t root = *rootId;
-        snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = root; wideFirst[0] = 0;
-        wideC0[0] = __float_as_int(rec[2 * (size_t)root].w); wideC1[0] = __float_as_int(rec[2 * (size_t)root + 1].w);
-    }
+    const float4* r = rec + kRec * (size_t)c;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    a.id = __float_as_int(r0.w); b.id = __float_as_int(r1.w);
+    a.count = __float_as_int(r2.w); b.count = __float_as_int(r3.w);
+    a.first = first; b.first = first + a.count;
+    cand_box(a, r0, r1); cand_box(b, r2, r3);
 }
 
-__global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint32_t* __restrict__ vals,
-    const float4* __restrict__ rec, const int32_t* __restrict__ count,
-    const int32_t* __restrict__ wideSrc, int32_t* __restrict__ wideC0, int32_t* __restrict__ wideC1, int32_t* __restrict__ wideFirst,
+__global__ void k_collapse_begin_p(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, int32_t* wideFirst, const int32_t* rootId)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = *rootId; wideFirst[0] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint32_t* __restrict__ vals, const float4* __restrict__ rec,
+    int32_t* __restrict__ wideSrc, int32_t* __restrict__ wideFirst,
     uint32_t* __restrict__ valsOut, const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter, float4* __restrict__ wide)
 {
     const int32_t begin = snap[0], end = snap[1];
@@ -1116,9 +1121,7 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
         CandP cd[4]; int ns = 0;
         if (active)
         {
-            const int32_t at = wideFirst[w];
-            cd[0] = cand_p(wideC0[w], at, n, rec, count);
-            cd[1] = cand_p(wideC1[w], at + cd[0].count, n, rec, count);
+            open_node(rec, wideSrc[w], wideFirst[w], cd[0], cd[1]);
             ns = 2;
             /* pass 0 opens inner subtrees (count > PT_LEAF_MAX), pass 1 spends leftover slots on splitting leaves */
             for (int pass = 0; pass < 2; ++pass)
@@ -1132,10 +1135,9 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
                         if (open && cd[k].area > bestArea) { best = k; bestArea = cd[k].area; }
                     }
                     if (best < 0) break;
-                    const int32_t c0 = cd[best].c0, c1 = cd[best].c1, at2 = cd[best].first;
-                    cd[best] = cand_p(c0, at2, n, rec, count);
-                    cd[ns] = cand_p(c1, at2 + cd[best].count, n, rec, count);
-                    ++ns;
+                    CandP a, b;
+                    open_node(rec, cd[best].id, cd[best].first, a, b);
+                    cd[best] = a; cd[ns] = b; ++ns;
                 }
             }
         }
@@ -1159,6 +1161,7 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
         if (!active) continue;
         int32_t next = base + incl - need;
         float lo[3][4], hi[3][4]; int32_t child[4];
+        float maxAbs = 0.0f;
         for (int k = 0; k < 4; ++k)
         {
             if (k >= ns)
@@ -1167,14 +1170,15 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
                 child[k] = PT_BVH_EMPTY;
                 continue;
             }
-            for (int a = 0; a < 3; ++a) { lo[a][k] = cd[k].lo[a]; hi[a][k] = cd[k].hi[a]; }
+            for (int a = 0; a < 3; ++a) { lo[a][k] = cd[k].lo[a]; hi[a][k] = cd[k].hi[a]; maxAbs = fmaxf(maxAbs, fmaxf(fabsf(cd[k].lo[a]), fabsf(cd[k].hi[a]))); }
             if (cd[k].count > PT_LEAF_MAX)
             {
-                child[k] = next; wideC0[next] = cd[k].c0; wideC1[next] = cd[k].c1; wideFirst[next] = cd[k].first; ++next;
+                child[k] = next; wideSrc[next] = cd[k].id; wideFirst[next] = cd[k].first; ++next;
             }
             else
             {
-                /* a leaf: its triangles go to their places in the tree order, left to right */
+                /* a leaf: its triangles go to their places in the tree order, left to right (an inner id here has at most
+                 * PT_LEAF_MAX leaves under it: their ids come from its line and its descendants') */
                 child[k] = ~((cd[k].first << 3) | (cd[k].count - 1));
                 int32_t todo[2 * PT_LEAF_MAX]; int top = 0, pos = cd[k].first;
                 todo[top++] = cd[k].id;
@@ -1182,8 +1186,7 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
                 {
                     const int32_t x = todo[--top];
                     if (x >= n - 1) valsOut[pos++] = vals[x - (n - 1)];
-                    else if (x == cd[k].id) { todo[top++] = cd[k].c1; todo[top++] = cd[k].c0; }
-                    else { todo[top++] = __float_as_int(rec[2 * (size_t)x + 1].w); todo[top++] = __float_as_int(rec[2 * (size_t)x].w); }
+                    else { const float4* r = rec + kRec * (size_t)x; todo[top++] = __float_as_int(r[1].w); todo[top++] = __float_as_int(r[0].w); }
                 }
             }
         }
@@ -1195,15 +1198,9 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
         q[4] = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
         q[5] = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
         q[6] = make_float4(__int_as_float(child[0]), __int_as_float(child[1]), __int_as_float(child[2]), __int_as_float(child[3]));
-        /* node 0's spare quad: the largest |coordinate| of the scene (traverse.h pads every box by an epsilon proportional to it) */
-        float maxAbs = 0.0f;
-        if (w == 0)
-        {
-            const int32_t rootSrc = wideSrc[0];
-            const float4 rl = rec[2 * (size_t)rootSrc], rh = rec[2 * (size_t)rootSrc + 1];
-            maxAbs = fmaxf(fmaxf(fmaxf(fabsf(rl.x), fabsf(rl.y)), fabsf(rl.z)), fmaxf(fmaxf(fabsf(rh.x), fabsf(rh.y)), fabsf(rh.z)));
-        }
-        q[7] = make_float4(maxAbs, 0.0f, 0.0f, 0.0f);
+        /* node 0's spare quad: the largest |coordinate| of the scene (traverse.h pads every box by an epsilon proportional to it);
+         * the root's slots together are the scene's box */
+        q[7] = make_float4(w == 0 ? maxAbs : 0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 
@@ -1343,7 +1340,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     const size_t oCLoA = take(sizeof(float4) * cap), oCHiA = take(sizeof(float4) * cap), oCLoB = take(sizeof(float4) * cap), oCHiB = take(sizeof(float4) * cap);
     const size_t oNn = take(4 * (size_t)cap), oKeep = take((size_t)cap), oBlockCount = take(4 * (size_t)plocBlocks + 4), oMergeCount = take(4 * (size_t)plocBlocks + 4);
     const size_t oCount = take(4 * (size_t)cap), oNewPos = take(4 * (size_t)cap), oVals2 = take(4 * (size_t)cap), oPloc = take(64);
-    const size_t oRec = take(sizeof(float4) * 2 * 2 * (size_t)cap);        /* packed records: lo, hi of inner node c at [2 c], of leaf i at [2 (n-1+i)] */
+    const size_t oRec = take(sizeof(float4) * 4 * (size_t)cap);        /* packed records: one 64-byte line per binary node (its children's boxes, ids, leaf counts) */
     const size_t need = off;
     if (b->capacityTris < cap || b->scratchBytes < need)
     {
@@ -1415,21 +1412,19 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     }
     else if (packed)
     {
-        k_ploc_init_p<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, rec, ploc);
-        const float4* loIn = rec + 2 * (size_t)(n - 1); const float4* hiIn = loIn + 1;           /* round 1 reads the leaves' records, which stay */
-        int32_t strideIn = 2;
-        float4* loOut = cLoA; float4* hiOut = cHiA;
+        k_ploc_init_p<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, cLoA, cHiA, ploc);
+        const float4* loIn = cLoA; const float4* hiIn = cHiA;
+        float4* loOut = cLoB; float4* hiOut = cHiB;
         int32_t mHost = n;
         int rounds = 0;
         while (mHost > kPlocFinish)
         {
             if (++rounds > 4096) { set_error("BVH build: clustering does not converge"); return PIMGPU_E_STATE; }
             const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
-            k_ploc_nn_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, strideIn, nn, keep, blockCount, mergeCount);
+            k_ploc_nn_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, 1, nn, keep, blockCount, mergeCount);
             k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
-            k_ploc_scatter_p<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, nn, blockCount, mergeCount, loIn, hiIn, strideIn, loOut, hiOut, rec, count);
-            loIn = loOut; hiIn = hiOut; strideIn = 1;
-            loOut = (loOut == cLoA) ? cLoB : cLoA; hiOut = (hiOut == cHiA) ? cHiB : cHiA;
+            k_ploc_scatter_p<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, nn, blockCount, mergeCount, loIn, hiIn, loOut, hiOut, rec);
+            { const float4* tl = loIn; const float4* th = hiIn; loIn = loOut; hiIn = hiOut; loOut = (float4*)tl; hiOut = (float4*)th; }
             if ((rounds & 3) == 0)
             {
                 PlocState hs;
@@ -1438,7 +1433,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
                 mHost = hs.m;
             }
         }
-        k_ploc_finish_p<<<1, kPlocFinish, 0, stream>>>(ploc, loIn, hiIn, strideIn, rec, count);
+        k_ploc_finish_p<<<1, kPlocFinish, 0, stream>>>(ploc, loIn, hiIn, rec);
         rootId = &ploc->rootId;
     }
     else
@@ -1480,7 +1475,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     if (!orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
     /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
      * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
-    if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, child0, child1, wideFirst, rootId, rec);
+    if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     else k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     int32_t hostSnap[kMaxWideLevels + 2];
     int level = 0;
@@ -1496,7 +1491,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             most = std::min<int64_t>(most, n);
             const int collapseGrid = (int)std::min<int64_t>((most + 255) / 256, kCollapseBlocks);
             if (packed)
-                k_collapse_level_p<<<collapseGrid, 256, 0, stream>>>(n, order, rec, count, wideSrc, child0, child1, wideFirst,
+                k_collapse_level_p<<<collapseGrid, 256, 0, stream>>>(n, order, rec, wideSrc, wideFirst,
                     vals2, snap + level, nodeCounter, b->nodes);
             else if (orderInCollapse)
                 k_collapse_level<true><<<collapseGrid, 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
