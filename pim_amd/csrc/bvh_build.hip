@@ -977,7 +977,9 @@ __global__ __launch_bounds__(256) void k_ploc_init_p(int32_t n, const uint32_t* 
     if (i == 0) { state->m = n; state->mPrev = n; state->nodeCounter = 0; state->rootId = n - 1; }
     if (i >= n) return;
     const uint32_t t = vals[i];
-    cLo[i] = with_w(triLo[t], (n - 1) + i); cHi[i] = with_w(triHi[t], 1);
+    /* a leaf's id names its TRIANGLE, not its Morton place (nothing asks for the place: a leaf's box travels in its parent's line),
+     * so the collapse writes the triangle order without a look-up through vals[] */
+    cLo[i] = with_w(triLo[t], (n - 1) + (int32_t)t); cHi[i] = with_w(triHi[t], 1);
 }
 
 __global__ __launch_bounds__(kPlocThreads) void k_ploc_scatter_p(const PlocState* __restrict__ state, const uint8_t* __restrict__ keep,
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
                 while (top > 0)
                 {
                     const int32_t x = todo[--top];
-                    if (x >= n - 1) valsOut[pos++] = vals[x - (n - 1)];
+                    if (x >= n - 1) valsOut[pos++] = (uint32_t)(x - (n - 1));
                     else { const float4* r = rec + kRec * (size_t)x; todo[top++] = __float_as_int(r[1].w); todo[top++] = __float_as_int(r[0].w); }
                 }
             }
