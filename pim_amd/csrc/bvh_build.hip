@@ -555,7 +555,7 @@ __device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t* sWav
 }
 
 __global__ __launch_bounds__(kScanThreads) void k_ploc_scan(PlocState* __restrict__ state, int32_t* __restrict__ blockCount, int32_t* __restrict__ mergeCount,
-    int32_t numBlocks)
+    int32_t numBlocks, int32_t* __restrict__ progress = nullptr, int32_t round = 0)
 {
     __shared__ int32_t sWave[kScanThreads / 64];
     const int32_t m = state->m;
@@ -573,7 +573,16 @@ __global__ __launch_bounds__(kScanThreads) void k_ploc_scan(PlocState* __restric
         const int32_t v = blockCount[b]; blockCount[b] = run; run += v;
         const int32_t u = mergeCount[b]; mergeCount[b] = ids; ids += u;
     }
-    if (threadIdx.x == 0) { state->mPrev = m; state->m = kept; state->nodeCounter = nodeBase + merged; }
+    if (threadIdx.x == 0)
+    {
+        state->mPrev = m; state->m = kept; state->nodeCounter = nodeBase + merged;
+        if (progress)
+        {
+            /* the host sizes the next launches from this without draining the stream: length first, then the round that made it */
+            __hip_atomic_store(progress + 0, kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(progress + 1, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 /* survivors move to the other list, order kept; a merging survivor becomes the new node */
@@ -1105,16 +1114,23 @@ __device__ __forceinline__ void open_node(const float4* __restrict__ rec, int32_
     cand_box(a, r0, r1); cand_box(b, r2, r3);
 }
 
-__global__ void k_collapse_begin_p(int32_t* snap, int32_t* nodeCounter, int32_t* wideSrc, int32_t* wideFirst, const int32_t* rootId)
+/* the packed collapse counts the nodes of each level in levelCount[level] (a level's kernel appends to the next level's count), so
+ * that a level's range is a prefix sum every block forms for itself and no copy sits between two levels' launches */
+__global__ void k_collapse_begin_p(int32_t* levelCount, int32_t* wideSrc, int32_t* wideFirst, const int32_t* rootId)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { snap[0] = 0; snap[1] = 1; *nodeCounter = 1; wideSrc[0] = *rootId; wideFirst[0] = 0; }
+    if (blockIdx.x != 0) return;
+    for (int l = threadIdx.x; l < kMaxWideLevels + 4; l += blockDim.x) levelCount[l] = l == 0 ? 1 : 0;
+    if (threadIdx.x == 0) { wideSrc[0] = *rootId; wideFirst[0] = 0; }
 }
 
 __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint32_t* __restrict__ vals, const float4* __restrict__ rec,
     int32_t* __restrict__ wideSrc, int32_t* __restrict__ wideFirst,
-    uint32_t* __restrict__ valsOut, const int32_t* __restrict__ snap, int32_t* __restrict__ nodeCounter, float4* __restrict__ wide)
+    uint32_t* __restrict__ valsOut, int32_t level, int32_t* __restrict__ levelCount, float4* __restrict__ wide)
 {
-    const int32_t begin = snap[0], end = snap[1];
+    int32_t begin = 0;
+    for (int l = 0; l < level; ++l) begin += levelCount[l];
+    const int32_t end = begin + levelCount[level];
+    int32_t* nextCount = levelCount + level + 1;
     __shared__ int32_t sTot[4], sBase;
     for (int32_t chunk = (int32_t)blockIdx.x; begin + chunk * (int32_t)blockDim.x < end; chunk += (int32_t)gridDim.x)
     {
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_collapse_level_p(int32_t n, const uint3
         if (threadIdx.x == 0)
         {
             const int total = sTot[0] + sTot[1] + sTot[2] + sTot[3];
-            sBase = total > 0 ? atomicAdd(nodeCounter, total) : 0;
+            sBase = end + (total > 0 ? atomicAdd(nextCount, total) : 0);
         }
         __syncthreads();
         int32_t base = sBase;
@@ -1307,7 +1323,8 @@ __global__ __launch_bounds__(256) void k_compress_nodes(const float4* __restrict
 void BvhStorage::release()
 {
     hipFree(nodes); hipFree(cnodes); hipFree(tris); hipFree(scratch);
-    nodes = nullptr; cnodes = nullptr; tris = nullptr; scratch = nullptr; scratchBytes = 0; capacityTris = 0;
+    if (progress) hipHostFree(progress);
+    nodes = nullptr; cnodes = nullptr; tris = nullptr; scratch = nullptr; progress = nullptr; scratchBytes = 0; capacityTris = 0;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1351,6 +1368,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         if (hipMalloc(&b->cnodes, sizeof(uint4) * 4 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
         if (hipMalloc(&b->tris, sizeof(float4) * 3 * ((size_t)cap + 1)) != hipSuccess) return PIMGPU_E_NOMEM;     /* + 1: traverse.h reads 64 B of a one-triangle leaf */
         if (hipMalloc(&b->scratch, need) != hipSuccess) return PIMGPU_E_NOMEM;
+        if (hipHostMalloc((void**)&b->progress, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return PIMGPU_E_NOMEM;
         b->capacityTris = cap; b->scratchBytes = need;
     }
     char* s = (char*)b->scratch;
@@ -1417,23 +1435,37 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         k_ploc_init_p<<<grid, 256, 0, stream>>>(n, vin, triLo, triHi, cLoA, cHiA, ploc);
         const float4* loIn = cLoA; const float4* hiIn = cHiA;
         float4* loOut = cLoB; float4* hiOut = cHiB;
+        /* The list length lives on the device.  Each round's scan reports it to pinned host memory, and the host stays at most
+         * kPlocLag rounds ahead of the last report: grids are sized by a length a few rounds old (blocks past the end return at once),
+         * the stream is never drained, and the few rounds launched after the list has become short enough for k_ploc_finish_p
+         * are ordinary rounds on a short list. */
+        constexpr int kPlocLag = 4;
+        volatile int32_t* progress = b->progress;
+        progress[0] = n; progress[1] = 0;
         int32_t mHost = n;
         int rounds = 0;
-        while (mHost > kPlocFinish)
+        for (;;)
         {
+            const int32_t want = rounds - kPlocLag + 1;
+            if (want > 0 && __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) < want)
+            {
+                for (uint32_t spins = 1; __atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) < want; ++spins)
+                {
+                    if ((spins & 0xFFFF) != 0) continue;
+                    const hipError_t q = hipStreamQuery(stream);        /* a stream that has failed or run dry never reports */
+                    if (q == hipErrorNotReady) continue;
+                    if (q != hipSuccess) return PIMGPU_E_DEVICE;
+                    if (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) < want) { set_error("BVH build: clustering round %d never reported", want); return PIMGPU_E_STATE; }
+                }
+            }
+            if (__atomic_load_n(&progress[1], __ATOMIC_ACQUIRE) > 0) mHost = std::min(mHost, (int32_t)progress[0]);
+            if (mHost <= kPlocFinish) break;
             if (++rounds > 4096) { set_error("BVH build: clustering does not converge"); return PIMGPU_E_STATE; }
             const int nb = (mHost + kPlocThreads - 1) / kPlocThreads;
             k_ploc_nn_merge<<<nb, kPlocThreads, 0, stream>>>(ploc, loIn, hiIn, 1, nn, keep, blockCount, mergeCount);
-            k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb);
+            k_ploc_scan<<<1, kScanThreads, 0, stream>>>(ploc, blockCount, mergeCount, nb, b->progress, rounds);
             k_ploc_scatter_p<<<nb, kPlocThreads, 0, stream>>>(ploc, keep, nn, blockCount, mergeCount, loIn, hiIn, loOut, hiOut, rec);
             { const float4* tl = loIn; const float4* th = hiIn; loIn = loOut; hiIn = hiOut; loOut = (float4*)tl; hiOut = (float4*)th; }
-            if ((rounds & 3) == 0)
-            {
-                PlocState hs;
-                if (hipMemcpyAsync(&hs, ploc, sizeof(hs), hipMemcpyDeviceToHost, stream) != hipSuccess) return PIMGPU_E_DEVICE;
-                if (hipStreamSynchronize(stream) != hipSuccess) return PIMGPU_E_DEVICE;
-                mHost = hs.m;
-            }
         }
         k_ploc_finish_p<<<1, kPlocFinish, 0, stream>>>(ploc, loIn, hiIn, rec);
         rootId = &ploc->rootId;
@@ -1477,7 +1509,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     if (!orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
     /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
      * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
-    if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
+    if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, wideSrc, wideFirst, rootId);          /* snap[]: nodes per level here */
     else k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     int32_t hostSnap[kMaxWideLevels + 2];
     int level = 0;
@@ -1485,7 +1517,11 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
     while (!done)
     {
         if (level >= kMaxWideLevels) { set_error("BVH collapse: more than %d levels", kMaxWideLevels); return PIMGPU_E_STATE; }
-        const int batchEnd = std::min(level + 8, kMaxWideLevels);
+        /* (the first batch is as long as trees of n leaves usually are deep -- about log2 n levels: a launch for a level that
+         * turns out empty costs a tenth of a drained stream) */
+        int firstBatch = 8;
+        while (firstBatch < 40 && ((int64_t)1 << firstBatch) < (int64_t)n) ++firstBatch;
+        const int batchEnd = std::min(level + (level == 0 ? firstBatch : 8), kMaxWideLevels);
         for (; level < batchEnd; ++level)
         {
             /* level L holds at most 4^L nodes and never more than the binary tree has inner nodes */
@@ -1493,9 +1529,11 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             most = std::min<int64_t>(most, n);
             const int collapseGrid = (int)std::min<int64_t>((most + 255) / 256, kCollapseBlocks);
             if (packed)
-                k_collapse_level_p<<<collapseGrid, 256, 0, stream>>>(n, order, rec, wideSrc, wideFirst,
-                    vals2, snap + level, nodeCounter, b->nodes);
-            else if (orderInCollapse)
+            {
+                k_collapse_level_p<<<collapseGrid, 256, 0, stream>>>(n, order, rec, wideSrc, wideFirst, vals2, level, snap, b->nodes);
+                continue;
+            }
+            if (orderInCollapse)
                 k_collapse_level<true><<<collapseGrid, 256, 0, stream>>>(n, order, triLo, triHi, nodeLo, nodeHi, child0, child1,
                     nullptr, count, wideSrc, wideFirst, vals2, snap + level, nodeCounter, b->nodes);
             else
@@ -1507,6 +1545,16 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         }
         if (hipMemcpyAsync(hostSnap, snap, sizeof(int32_t) * (size_t)(level + 2), hipMemcpyDeviceToHost, stream) != hipSuccess) return PIMGPU_E_DEVICE;
         if (hipStreamSynchronize(stream) != hipSuccess) return PIMGPU_E_DEVICE;
+        if (packed)
+        {
+            int32_t total = 0;
+            for (int l = 0; l <= level && !done; ++l)
+            {
+                if (hostSnap[l] == 0) { done = true; b->depth = l; b->nodeCount = total; }
+                total += hostSnap[l];
+            }
+            continue;
+        }
         for (int l = 0; l <= level; ++l)
         {
             if (hostSnap[l + 1] == hostSnap[l]) { done = true; b->depth = l; b->nodeCount = hostSnap[l]; break; }

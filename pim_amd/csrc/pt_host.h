@@ -22,6 +22,7 @@ struct BvhStorage
     int32_t triCount = 0;
     int32_t nodeCount = 0;
     int32_t depth = 0;                  /* levels of the 4-wide tree of the last build */
+    int32_t* progress = nullptr;        /* pinned host memory the clustering rounds report to: [0] list length, [1] rounds done */
     void release();
     DBvh view() const { DBvh b; b.nodes = nodes; b.cnodes = cnodes; b.tris = tris; b.nodeCount = nodeCount; b.triCount = triCount; return b; }
 };
