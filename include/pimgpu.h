@@ -382,11 +382,12 @@ int pimgpu_trace_buffers(const PimTrace* trace, void** colorDev, void** albedoDe
 /* the same buffers copied device-to-device into caller-owned HBM (any pointer may be NULL): what a multi-GPU
  * caller hands to an RCCL reduce */
 int pimgpu_trace_copy_dev(const PimTrace* trace, void* colorDst, void* albedoDst, void* normalDst);
-/* CalcStdDev (render_system.c:1374-1394) on the device colour buffer */
+/* CalcStdDev (render_system.c:1374-1394) on the device colour buffer: the reference's two serial fp32 sums in pixel order, bit for
+ * bit (formed in parallel where the terms allow it, by the one-wave chain otherwise; PIMGPU_STDDEV_SERIAL=1 forces the chain) */
 int pimgpu_trace_stddev(const PimTrace* trace, float* meanOut, float* stddevOut);
 /* NO COUNTERPART IN THE REFERENCE.  pimgpu_trace_stddev for callers that cannot allocate (tight serving loops, harnesses that
  * forbid hipMalloc after set-up): same result bit for bit, but the per-pixel terms live in a file-scope device array of the
- * library (31.6 MiB per GPU, held until the process ends) instead of a work buffer grown on demand, and the two floats come
+ * library (31.9 MiB per GPU, held until the process ends) instead of a work buffer grown on demand, and the two floats come
  * back through a page-locked block made at pimgpu_init.  The call is synchronous (a device-to-host copy and a stream wait), so
  * it cannot run under HIP graph capture.  Limit: width*height <= 3840*2160, else PIMGPU_E_LIMIT.  The array belongs to the GPU:
  * all contexts on one GPU (a device listed twice in pimgpu_init_devices) and all concurrent callers share it, so calls that

@@ -955,18 +955,24 @@ __global__ __launch_bounds__(256) void k_resolve_image(const PimResult* __restri
 /* CalcStdDev, render_system.c:1374-1394.  The reference accumulates mean and variance serially in fp32, in
  * pixel order, and that order is part of the result.  Per-pixel terms are computed in parallel (k_stddev_terms);
  * the two running sums are then formed in pixel order by one wave (k_stddev_sum). */
+struct FsState;
+__device__ void fs_flag_term(FsState* st, float term);
+
 __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ color, int32_t len, const float* __restrict__ meanIn,
-    float* __restrict__ terms)
+    float* __restrict__ terms, FsState* __restrict__ fast = nullptr)
 {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const float lum = (color[i * 3] + color[i * 3 + 1] + color[i * 3 + 2]) * (1.0f / 3.0f);
-    if (!meanIn) terms[i] = lum * (1.0f / len);                       /* mean += lum * meanWeight */
+    float term;
+    if (!meanIn) term = lum * (1.0f / len);                           /* mean += lum * meanWeight */
     else
     {
         const float err = lum - meanIn[0];
-        terms[i] = (1.0f / (len - 1)) * (err * err);                  /* variance += varianceWeight * (err * err) */
+        term = (1.0f / (len - 1)) * (err * err);                      /* variance += varianceWeight * (err * err) */
     }
+    terms[i] = term;
+    if (fast) fs_flag_term(fast, term);
 }
 
 /*
@@ -981,12 +987,29 @@ __global__ __launch_bounds__(256) void k_stddev_terms(const float* __restrict__ 
  */
 static constexpr int kSumRing = 48;         /* float4 loads in flight */
 static constexpr int kSumBody = 4 * kSumRing;   /* float4 per pass of the loop: straight-line code, nothing carried around the back edge */
-__global__ __launch_bounds__(128) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut)
+struct FsState { float acc; int32_t pos, done, bad, mapsFrom, mapsE, mapsHaveAcc, rounds; };   /* k_fs_* below */
+
+__global__ __launch_bounds__(128) void k_stddev_sum(const float* __restrict__ terms, int32_t len, float* __restrict__ out, int32_t sqrtOut,
+    const FsState* __restrict__ fast = nullptr)
 {
     const float4* __restrict__ t4 = (const float4*)terms + (threadIdx.x >> 6);       /* == terms: the launch has one wave */
     const int32_t n4 = len >> 2;
     float acc = 0.0f;
     int32_t i = 0;
+    if (fast)
+    {
+        /* behind the parallel sum (k_fs_*): nothing to do when it finished; from the start when it saw a term it does not take;
+         * else from where it stopped */
+        if (fast->done) return;
+        if (!fast->bad)
+        {
+            acc = fast->acc;
+            int32_t j = fast->pos;
+            for (; j < len && (j & 3) != 0; ++j) acc = acc + terms[j + (threadIdx.x >> 6)];
+            if (j >= len) { if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(acc) : acc; return; }
+            i = j >> 2;
+        }
+    }
     /* One pass: kSumRing loads up front (their latency is paid once per pass, ~600 of ~3700 cycles), then every group of four
      * additions is followed by the reload of its registers for 48 groups later.  The ring is NOT carried around the loop: carried,
      * the register allocator rotated it with one v_mov per v_add on the chain's own issue slots (5.5 ns per term). */
@@ -1007,14 +1030,285 @@ __global__ __launch_bounds__(128) void k_stddev_sum(const float* __restrict__ te
     if (threadIdx.x == 0) out[0] = sqrtOut ? pt_sqrt(acc) : acc;
 }
 
+/*
+ * The same serial sum, formed in parallel.  "The order is the result" holds for fp32 additions in general, but these sums add
+ * terms >= 0 to a running sum that only grows, and while the sum stays inside one binade [2^e, 2^(e+1)) an fp32 addition is an
+ * INTEGER addition: with q = 2^(e-23) the sum is A * q for an integer A in [2^23, 2^24), a term is tau * q for a real tau, and
+ *     fl(A q + tau q) = (A + floor(tau) + [frac(tau) > 1/2] + [frac(tau) == 1/2 and A + floor(tau) odd]) * q
+ * as long as the result stays below 2^24 q.  So a run of terms acts on A as "add an integer that depends on nothing but the
+ * parity of A on entry" -- a pair of integers (increment for even A, increment for odd A) -- and such pairs compose
+ * associatively: runs can be summarised in parallel and combined in order.  Only the additions that carry the sum into the
+ * next binade (at most 254 of them in fp32, about 23 for a 4K frame) are done as real fp32 additions, one by one.
+ *
+ *   k_fs_maps   every 4096-term chunk not yet begun -> its pair for each of kFsCands binades starting at the current one
+ *   k_fs_walk   one workgroup: combines the chunks' pairs in order (a scan), finds the first chunk in which the sum would leave
+ *               its binade, goes through that chunk term by term (scan over its 4096 terms), does the crossing addition in
+ *               fp32, goes on in the new binade; stops when the binade has left the range the pairs were made for
+ *   ... launched kFsRounds times back to back without the host looking (a finished sum makes the rest return at once), and
+ *   k_stddev_sum behind them takes over from wherever they stopped: if the rounds did not suffice, or if a term is negative,
+ *   NaN, infinite or denormal (k_stddev_terms flags those; then the chain runs from the start as before).
+ * Same additions in the same order with the same roundings: the bits are those of the chain (tests/test_gpu_stddev_sum.py
+ * compares the two on images made of ties, zeros, single bright pixels and wide ranges), a 4K pt_stddev (two sums) 71.7 -> 0.76 ms.
+ */
+static constexpr int kFsChunk = 4096, kFsCands = 8, kFsRounds = 5, kFsWalkThreads = 1024, kFsDetailBudget = 8;
+static constexpr int32_t kFsHuge = 1 << 25;                     /* "leaves the binade for certain" */
+static constexpr long long kFsTop = 1ll << 24;
+struct FsMap { long long a0, a1; };                             /* increment of A for even / odd A on entry */
+
+__device__ void fs_flag_term(FsState* st, float term)
+{
+    const uint32_t u = __float_as_uint(term), ex = (u >> 23) & 0xFFu, mant = u & 0x7FFFFFu;
+    const bool bad = ex == 0xFFu || (ex == 0u && mant != 0u) || ((u >> 31) != 0u && (u << 1) != 0u);
+    if (bad) atomicOr(&st->bad, 1);
+}
+
+__device__ __forceinline__ FsMap fs_then(FsMap g, FsMap f)      /* g first, then f */
+{
+    FsMap h;
+    h.a0 = g.a0 + ((g.a0 & 1) ? f.a1 : f.a0);
+    h.a1 = g.a1 + (((1 + g.a1) & 1) ? f.a1 : f.a0);
+    return h;
+}
+
+/* what adding the term with bits u does to A while the sum is in binade e: A += k + (tie & (A + k) & 1) */
+__device__ __forceinline__ void fs_classify(uint32_t u, int e, bool haveAcc, int32_t& k, int32_t& tie)
+{
+    k = 0; tie = 0;
+    const uint32_t ex = (u >> 23) & 0xFFu;
+    if (ex == 0u) return;                                       /* zero */
+    if (!haveAcc) { k = kFsHuge; return; }                      /* the sum is still 0: the first term that is not starts it */
+    const uint32_t m = (u & 0x7FFFFFu) | 0x800000u;
+    const int s = (int)ex - 127 - e;                            /* tau = m * 2^(s - 23) */
+    if (s >= 0) { k = kFsHuge; return; }                        /* tau >= 2^23 and A >= 2^23: leaves the binade */
+    const int r = -s;
+    if (r > 24) return;                                         /* tau < 1/2 */
+    const uint32_t rem = m & ((1u << r) - 1u), half = 1u << (r - 1);
+    k = (int32_t)(m >> r) + (rem > half ? 1 : 0);
+    tie = rem == half ? 1 : 0;
+}
+
+__device__ __forceinline__ void fs_apply(long long& A, int32_t k, int32_t tie) { A += k + (tie & (int32_t)((A + k) & 1)); }
+
+__global__ __launch_bounds__(256) void k_fs_maps(const float* __restrict__ terms, int32_t len, FsState* __restrict__ st, FsMap* __restrict__ maps)
+{
+    if (st->done | st->bad) return;
+    const int32_t pos = st->pos;
+    const int32_t first = (pos + kFsChunk - 1) / kFsChunk;      /* the chunk pos stands in (if inside one) is the walk's own */
+    const uint32_t accBits = __float_as_uint(st->acc);
+    const bool haveAcc = accBits != 0u;
+    const int eBase = (int)((accBits >> 23) & 0xFFu) - 127;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->mapsFrom = first; st->mapsE = eBase; st->mapsHaveAcc = haveAcc ? 1 : 0; }
+    const int32_t c = (int32_t)blockIdx.x;
+    if (c < first || (long long)c * kFsChunk >= len) return;
+    /* a thread's 16 terms in a row, and their pair for every candidate binade */
+    constexpr int kPer = kFsChunk / 256;
+    const int32_t base = c * kFsChunk + (int32_t)threadIdx.x * kPer;
+    uint32_t u[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer / 4; ++q)
+    {
+        const int32_t j = base + q * 4;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (j + 3 < len) v = *(const uint4*)(terms + j);
+        else { if (j < len) v.x = __float_as_uint(terms[j]); if (j + 1 < len) v.y = __float_as_uint(terms[j + 1]); if (j + 2 < len) v.z = __float_as_uint(terms[j + 2]); }
+        u[q * 4 + 0] = v.x; u[q * 4 + 1] = v.y; u[q * 4 + 2] = v.z; u[q * 4 + 3] = v.w;
+    }
+    __shared__ FsMap sMap[256][kFsCands];
+#pragma unroll
+    for (int cand = 0; cand < kFsCands; ++cand)
+    {
+        long long a0 = 0, a1 = 1;                               /* A itself (even / odd start), less the start at the end */
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+        {
+            int32_t k, tie; fs_classify(u[q], eBase + cand, haveAcc, k, tie);
+            fs_apply(a0, k, tie); fs_apply(a1, k, tie);
+        }
+        sMap[threadIdx.x][cand].a0 = a0; sMap[threadIdx.x][cand].a1 = a1 - 1;
+    }
+    for (int half = 1; half < 256; half <<= 1)
+    {
+        __syncthreads();
+        const int items = (128 / half) * kFsCands;
+        for (int item = threadIdx.x; item < items; item += 256)
+        {
+            const int cand = item % kFsCands, i = (item / kFsCands) * 2 * half;
+            sMap[i][cand] = fs_then(sMap[i][cand], sMap[i + half][cand]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kFsCands) maps[(size_t)c * kFsCands + threadIdx.x] = sMap[0][threadIdx.x];
+}
+
+/* exclusive scan of the workgroup's pairs in thread order (kFsWalkThreads threads); *total = all of them */
+__device__ FsMap fs_scan(FsMap own, FsMap* sWave, FsMap* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FsMap incl = own;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        FsMap prev; prev.a0 = __shfl_up(incl.a0, o, 64); prev.a1 = __shfl_up(incl.a1, o, 64);
+        if (lane >= o) incl = fs_then(prev, incl);
+    }
+    FsMap excl; excl.a0 = __shfl_up(incl.a0, 1, 64); excl.a1 = __shfl_up(incl.a1, 1, 64);
+    if (lane == 0) { excl.a0 = 0; excl.a1 = 0; }
+    __syncthreads();                                            /* the scan before this one has been read */
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    FsMap before; before.a0 = 0; before.a1 = 0;
+    FsMap all; all.a0 = 0; all.a1 = 0;
+    for (int w = 0; w < kFsWalkThreads / 64; ++w) { if (w == wave) before = all; all = fs_then(all, sWave[w]); }
+    *total = all;
+    return fs_then(before, excl);
+}
+
+/* smallest value of the workgroup (INT_MAX: none) */
+__device__ int32_t fs_min(int32_t v, int32_t* sMin)
+{
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sMin[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int32_t m = 0x7FFFFFFF;
+    for (int w = 0; w < kFsWalkThreads / 64; ++w) m = min(m, sMin[w]);
+    return m;
+}
+
+__global__ __launch_bounds__(kFsWalkThreads) void k_fs_walk(const float* __restrict__ terms, int32_t len, FsState* __restrict__ st,
+    const FsMap* __restrict__ maps, float* __restrict__ out, int32_t sqrtOut)
+{
+    if (st->done | st->bad) return;
+    __shared__ FsMap sWave[kFsWalkThreads / 64];
+    __shared__ int32_t sMin[kFsWalkThreads / 64];
+    __shared__ long long sBefore;
+    __shared__ uint32_t sTerm;
+    /* the state, the same in every thread: the sum is A * 2^(e - 23), or 0 (haveAcc false), or has overflowed (isInf) */
+    uint32_t accBits = __float_as_uint(st->acc);
+    int32_t pos = st->pos;
+    const int32_t mapsFrom = st->mapsFrom, mapsE = st->mapsE, mapsHaveAcc = st->mapsHaveAcc;
+    bool haveAcc = accBits != 0u, isInf = false;
+    int e = (int)((accBits >> 23) & 0xFFu) - 127;
+    long long A = haveAcc ? (long long)((accBits & 0x7FFFFFu) | 0x800000u) : 0;
+    const int32_t chunks = (len + kFsChunk - 1) / kFsChunk;
+    int budget = kFsDetailBudget;
+    for (;;)
+    {
+        if (pos >= len || isInf) break;
+        int32_t c = pos / kFsChunk;
+        const bool aligned = pos == c * kFsChunk;
+        const int cand = e - mapsE;
+        const bool valid = aligned && c >= mapsFrom && (mapsHaveAcc != 0) == haveAcc && (!haveAcc || (cand >= 0 && cand < kFsCands));
+        if (valid)
+        {
+            /* the chunks' pairs in order: where does the sum leave this binade? */
+            const int32_t todo = chunks - c, per = (todo + kFsWalkThreads - 1) / kFsWalkThreads;
+            const int32_t c0 = min(c + (int32_t)threadIdx.x * per, chunks), c1 = min(c0 + per, chunks);
+            const int useCand = haveAcc ? cand : 0;
+            FsMap own; own.a0 = 0; own.a1 = 0;
+            for (int32_t x = c0; x < c1; ++x) own = fs_then(own, maps[(size_t)x * kFsCands + useCand]);
+            FsMap total;
+            const FsMap excl = fs_scan(own, sWave, &total);
+            long long a = A + ((A & 1) ? excl.a1 : excl.a0);
+            int32_t found = 0x7FFFFFFF; long long before = 0;
+            for (int32_t x = c0; x < c1; ++x)
+            {
+                const FsMap m = maps[(size_t)x * kFsCands + useCand];
+                const long long next = a + ((a & 1) ? m.a1 : m.a0);
+                if (next >= kFsTop) { found = x; before = a; break; }
+                a = next;
+            }
+            const int32_t hit = fs_min(found, sMin);
+            if (hit == 0x7FFFFFFF) { A += (A & 1) ? total.a1 : total.a0; pos = len; break; }
+            if (found == hit) sBefore = before;
+            __syncthreads();
+            A = sBefore; c = hit; pos = hit * kFsChunk;
+        }
+        else if (aligned)
+        {
+            if (budget == 0) break;                             /* the next k_fs_maps makes pairs for this binade */
+            --budget;
+        }
+        /* chunk c term by term, from pos to its end */
+        const int32_t chunkEnd = min((c + 1) * kFsChunk, len);
+        while (pos < chunkEnd && !isInf)
+        {
+            const int32_t j0 = c * kFsChunk + (int32_t)threadIdx.x * 4;
+            uint32_t u[4];
+            for (int q = 0; q < 4; ++q) { const int32_t j = j0 + q; u[q] = (j >= pos && j < len) ? __float_as_uint(terms[j]) : 0u; }
+            long long a0 = 0, a1 = 1;
+            for (int q = 0; q < 4; ++q) { int32_t k, tie; fs_classify(u[q], e, haveAcc, k, tie); fs_apply(a0, k, tie); fs_apply(a1, k, tie); }
+            FsMap own; own.a0 = a0; own.a1 = a1 - 1;
+            FsMap total;
+            const FsMap excl = fs_scan(own, sWave, &total);
+            long long a = A + ((A & 1) ? excl.a1 : excl.a0);
+            int32_t found = 0x7FFFFFFF; long long before = 0; uint32_t term = 0u;
+            for (int q = 0; q < 4; ++q)
+            {
+                int32_t k, tie; fs_classify(u[q], e, haveAcc, k, tie);
+                long long next = a; fs_apply(next, k, tie);
+                if (next >= kFsTop) { found = j0 + q; before = a; term = u[q]; break; }
+                a = next;
+            }
+            const int32_t hit = fs_min(found, sMin);
+            if (hit == 0x7FFFFFFF) { A += (A & 1) ? total.a1 : total.a0; pos = chunkEnd; break; }
+            if (found == hit) { sBefore = before; sTerm = term; }
+            __syncthreads();
+            /* the addition that leaves the binade: in fp32, as the chain does it */
+            const long long ab = sBefore;
+            const float accBefore = haveAcc ? __uint_as_float(((uint32_t)(e + 127) << 23) | ((uint32_t)ab & 0x7FFFFFu)) : 0.0f;
+            const float accNew = accBefore + __uint_as_float(sTerm);
+            accBits = __float_as_uint(accNew);
+            if (((accBits >> 23) & 0xFFu) == 0xFFu) { isInf = true; break; }
+            haveAcc = true;
+            e = (int)((accBits >> 23) & 0xFFu) - 127;
+            A = (long long)((accBits & 0x7FFFFFu) | 0x800000u);
+            pos = hit + 1;
+        }
+    }
+    const float acc = isInf ? __builtin_inff() : (haveAcc ? __uint_as_float(((uint32_t)(e + 127) << 23) | ((uint32_t)A & 0x7FFFFFu)) : 0.0f);
+    if (threadIdx.x == 0)
+    {
+        const bool done = pos >= len || isInf;
+        st->acc = acc; st->pos = pos; st->done = done ? 1 : 0; st->rounds += 1;
+        if (done) out[0] = sqrtOut ? pt_sqrt(acc) : acc;
+    }
+}
+
+/* the launches of one sum: parallel rounds, then the chain for whatever they left (usually nothing).  head: FsState + the chunks' pairs */
+static constexpr int32_t kFsStateFloats = 16;
+static int64_t fs_head_floats(int64_t len) { return kFsStateFloats + ((len + kFsChunk - 1) / kFsChunk + 1) * kFsCands * (int64_t)(sizeof(FsMap) / sizeof(float)); }
+static bool fs_serial_only() { const char* v = getenv("PIMGPU_STDDEV_SERIAL"); return v && v[0] == '1'; }     /* read per call: the tests switch it */
+
+static void stddev_sum_launch(const float* color, int32_t len, const float* meanIn, float* terms, float* head, float* out, int32_t sqrtOut, hipStream_t stream)
+{
+    if (fs_serial_only())
+    {
+        k_stddev_terms<<<(len + 255) / 256, 256, 0, stream>>>(color, len, meanIn, terms);
+        k_stddev_sum<<<1, 64, 0, stream>>>(terms, len, out, sqrtOut);
+        return;
+    }
+    FsState* st = (FsState*)head;
+    FsMap* maps = (FsMap*)(head + kFsStateFloats);
+    hipMemsetAsync(st, 0, sizeof(FsState), stream);
+    k_stddev_terms<<<(len + 255) / 256, 256, 0, stream>>>(color, len, meanIn, terms, st);
+    const int32_t chunks = (len + kFsChunk - 1) / kFsChunk;
+    for (int r = 0; r < kFsRounds; ++r)
+    {
+        k_fs_maps<<<chunks, 256, 0, stream>>>(terms, len, st, maps);
+        k_fs_walk<<<1, kFsWalkThreads, 0, stream>>>(terms, len, st, maps, out, sqrtOut);
+    }
+    k_stddev_sum<<<1, 64, 0, stream>>>(terms, len, out, sqrtOut, st);
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* scratch of pimgpu_trace_stddev_noalloc: the per-pixel terms CalcStdDev's two serial sums walk over, and the two results.
  * A file-scope device array instead of the grown-on-demand work buffer of pimgpu_trace_stddev, for callers that cannot
- * call hipMalloc.  Every GPU holds its own copy (kStddevScratchFloats * 4 bytes = 31.6 MiB) until the process ends.  The
+ * call hipMalloc.  Every GPU holds its own copy (kStddevScratchFloats * 4 bytes = 31.9 MiB) until the process ends.  The
  * array's NAME is a host-side stand-in, not a device address: host code only ever uses the per-device address that
  * hipGetSymbolAddress returned at pimgpu_init (stddev_scratch_setup below). */
 static constexpr int32_t kStddevNoAllocMaxPixels = 3840 * 2160;
-static constexpr int32_t kStddevScratchHead = 64;                 /* floats in front of the terms: [0] mean, [1] stddev */
+/* floats in front of the terms: [0] mean, [1] stddev, from [64] the parallel sum's state and per-chunk pairs (fs_head_floats) */
+static constexpr int32_t kStddevScratchHead = 64 + ((kFsStateFloats + (kStddevNoAllocMaxPixels / kFsChunk + 2) * kFsCands * (int32_t)(sizeof(FsMap) / sizeof(float)) + 63) / 64) * 64;
 static constexpr size_t kStddevScratchFloats = (size_t)kStddevNoAllocMaxPixels + kStddevScratchHead;
 static __device__ __align__(256) float scratch[kStddevScratchFloats];
 static constexpr int kScratchMaxDevices = 64;
@@ -1841,12 +2135,12 @@ int pimgpu_trace_stddev(const PimTrace* t, float* meanOut, float* stddevOut)
     float* outDev = (float*)g_lib.trace.status + 16;       /* spare words of the status block */
     const int32_t len = t->width * t->height;
     WorkBuffers& w = g_lib.work;
-    if ((rc = w.ensure_rays((len + 3) / 4 + 1))) return rc;  /* len floats of scratch in the packed-ray buffer */
-    float* terms = (float*)w.rayO;
-    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, nullptr, terms);
-    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev, 0);
-    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
-    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
+    const int64_t headFloats = (fs_head_floats(len) + 63) / 64 * 64;
+    if ((rc = w.ensure_rays((len + headFloats + 3) / 4 + 1))) return rc;  /* head + len floats of scratch in the packed-ray buffer */
+    float* head = (float*)w.rayO;
+    float* terms = head + headFloats;
+    stddev_sum_launch(t->color, len, nullptr, terms, head, outDev, 0, g_lib.stream);
+    stddev_sum_launch(t->color, len, outDev, terms, head, outDev + 1, 1, g_lib.stream);
     float h[2];
     PT_HIP(hipMemcpyAsync(h, outDev, sizeof(h), hipMemcpyDeviceToHost, g_lib.stream));
     PT_HIP(hipStreamSynchronize(g_lib.stream));
@@ -1878,10 +2172,8 @@ int pimgpu_trace_stddev_noalloc(const PimTrace* t, float* meanOut, float* stddev
     const int32_t len = (int32_t)len64;
     float* outDev = base;
     float* terms = base + kStddevScratchHead;
-    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, nullptr, terms);
-    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev, 0);
-    k_stddev_terms<<<(len + 255) / 256, 256, 0, g_lib.stream>>>(t->color, len, outDev, terms);
-    k_stddev_sum<<<1, 64, 0, g_lib.stream>>>(terms, len, outDev + 1, 1);
+    stddev_sum_launch(t->color, len, nullptr, terms, base + 64, outDev, 0, g_lib.stream);
+    stddev_sum_launch(t->color, len, outDev, terms, base + 64, outDev + 1, 1, g_lib.stream);
     PT_HIP(hipGetLastError());
     float* h = g_lib.smallBack;                             /* page-locked, made at pimgpu_init: the copy is not staged */
     if (!h) { set_error("trace_stddev_noalloc: no read-back block (pimgpu_init)"); return PIMGPU_E_STATE; }
