@@ -348,7 +348,10 @@ def microbench_roofline(name, n, dt, b_ray, alg, nodes, tris, worst):
     if pk.get("hbm_bytes_per_unit") is not None:
         g = n * pk["hbm_bytes_per_unit"] / dt / 1e9
         e["ceilings"]["hbm"] = {"achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS, "bytes_per_unit": pk["hbm_bytes_per_unit"],
-                                "l2_hit_rate": pk.get("l2_hit_rate"), "source": src}
+                                "l2_hit_rate": pk.get("l2_hit_rate"), "source": src,
+                                # the fabric moves 128-byte lines, and serves random line requests at a measured 46-57 G/s (a coalesced
+                                # stream: 45-47 G/s): profiles/r03_gather_calibration.txt, scripts/micro/gather.hip
+                                "line_requests_per_s": g * 1e9 / 128.0, "random_line_request_ceiling_measured": [46e9, 57e9]}
         e["traffic"] = n * pk["hbm_bytes_per_unit"]
     measured = {k: v for k, v in e["ceilings"].items() if k != "cache"} or e["ceilings"]
     name = max(measured, key=lambda k: measured[k]["frac"])
