@@ -404,6 +404,16 @@ __global__ __launch_bounds__(256) void k_ploc_init(int32_t n, const uint32_t* __
     cLo[i] = triLo[t]; cHi[i] = triHi[t];
 }
 
+/* is neighbour j (merged area a) a better choice for cluster `self` than bestJ (area best)?  Smaller area; among EQUAL areas the
+ * neighbour with the smaller (self xor j) -- a rule that is the same seen from either side, so a run of clusters with equal boxes
+ * (coincident triangles: duplicated geometry, points) pairs up as (0,1) (2,3) ... and halves every round.  With "the lower index
+ * wins" only one pair of such a run was mutual per round: 1500 copies of a triangle took 1500 rounds and gave a chain deeper than
+ * the collapse's level table (tests/test_gpu_build_edges.py). */
+__device__ __forceinline__ bool ploc_better(float a, float best, int32_t self, int32_t j, int32_t bestJ)
+{
+    return a < best || (a == best && (uint32_t)(self ^ j) < (uint32_t)(self ^ bestJ));
+}
+
 /* nearest neighbour by merged surface area within +-kPlocRadius; the block's boxes are staged through LDS */
 __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn(const PlocState* __restrict__ state,
     const float4* __restrict__ cLo, const float4* __restrict__ cHi, int32_t* __restrict__ nn, int32_t stride = 1)
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn(const PlocState* __res
         const int32_t j = i + d;
         if (d == 0 || j < 0 || j >= m) continue;
         const float a = ploc_area(lo, hi, sLo[threadIdx.x + kPlocRadius + d], sHi[threadIdx.x + kPlocRadius + d]);
-        if (a < best) { best = a; bestJ = j; }          /* ascending j: ties keep the lower index */
+        if (ploc_better(a, best, i, j, bestJ)) { best = a; bestJ = j; }
     }
     nn[i] = bestJ;
 }
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(kPlocThreads) void k_ploc_nn_merge(const PlocState*
                 const int32_t j = e + d;
                 if (d == 0 || j < 0 || j >= m) continue;
                 const float a = ploc_area(lo, hi, sLo[k + R + d], sHi[k + R + d]);
-                if (a < best) { best = a; bestJ = j; }          /* ascending j: ties keep the lower index */
+                if (ploc_better(a, best, e, j, bestJ)) { best = a; bestJ = j; }
             }
         }
         sNn[k] = bestJ;
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish(int32_t n, PlocStat
                 const int32_t j = t + d;
                 if (d == 0 || j < 0 || j >= m) continue;
                 const float a = ploc_area(sLo[cur][t], sHi[cur][t], sLo[cur][j], sHi[cur][j]);
-                if (a < best) { best = a; bestJ = j; }
+                if (ploc_better(a, best, t, j, bestJ)) { best = a; bestJ = j; }
             }
             sNn[t] = bestJ;
         }
@@ -1049,7 +1059,7 @@ __global__ __launch_bounds__(kPlocFinish) void k_ploc_finish_p(PlocState* __rest
                 const int32_t j = t + d;
                 if (d == 0 || j < 0 || j >= m) continue;
                 const float a = ploc_area(sLo[cur][t], sHi[cur][t], sLo[cur][j], sHi[cur][j]);
-                if (a < best) { best = a; bestJ = j; }
+                if (ploc_better(a, best, t, j, bestJ)) { best = a; bestJ = j; }
             }
             sNn[t] = bestJ;
         }
