@@ -48,7 +48,10 @@ def _render_both(sc, W, H, frames, max_bounces, cam=None, check_lights=True):
             assert_bits_equal(color, img[0], f"color (switch {switch})")
             assert_bits_equal(albedo, img[1], f"albedo (switch {switch})")
             assert_bits_equal(normal, img[2], f"normal (switch {switch})")
-            assert t.stddev() == (mo, sod)
+            # bits, except that a NaN is a NaN: a 1x1 image's stddev is inf * 0, and the default NaN of an invalid operation is
+            # 0xFFC00000 on x86 and 0x7FC00000 on gfx950
+            for got_v, want_v in zip(t.stddev(), (mo, sod)):
+                assert (np.isnan(got_v) and np.isnan(want_v)) or np.float32(got_v).tobytes() == np.float32(want_v).tobytes(), (got_v, want_v)
             if check_lights:
                 gl = g.download_lights()
                 for k in ("live", "pdf", "cdf"):
@@ -166,3 +169,10 @@ def test_tiny_scenes_render_bit_exact(ntri):
     if ntri:
         b.add_arrays(full.positions[:ntri * 3], full.normals[:ntri * 3], full.uvs[:ntri * 3], m)
     _render_both(b.build(), 64, 36, 2, 4)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 9), (130, 1), (67, 35), (2, 2)])
+def test_image_sizes_that_fill_no_wave_or_row_bit_exact(W, H):
+    """a single pixel (pt_stddev divides by N - 1 = 0 there: whatever the reference's arithmetic gives), one column, one row
+    wider than two waves, and sizes that are multiples of nothing, three frames each"""
+    _render_both(scenes.cornell_box(), W, H, 3, 4)
