@@ -176,3 +176,9 @@ def test_image_sizes_that_fill_no_wave_or_row_bit_exact(W, H):
     """a single pixel (pt_stddev divides by N - 1 = 0 there: whatever the reference's arithmetic gives), one column, one row
     wider than two waves, and sizes that are multiples of nothing, three frames each"""
     _render_both(scenes.cornell_box(), W, H, 3, 4)
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2])
+def test_bounce_limits_at_the_bottom_bit_exact(bounces):
+    """no bounce at all (the loop body never runs: the reference's result is what Pt_TraceRay initialises), one, two"""
+    _render_both(scenes.cornell_box(), 48, 27, 2, bounces)

@@ -67,3 +67,28 @@ def test_resident_pages_bake_like_host_pages():
     with pytest.raises(api.PimGpuError):
         api.LightmapSet(0, S)
     lm.close(); g.close()
+
+
+@pytest.mark.parametrize("S,tpu", [(1, 0.05), (3, 0.25), (37, 1.5)])
+def test_bake_edge_sizes_ranges_and_slices_bit_exact(S, tpu):
+    """page sizes that are multiples of nothing (a 1 x 1 page), an empty texel range, ranges that cross the page boundary, a page
+    with no mapped texel at all, and a time slice so thin that a pass may sample nothing"""
+    gpu_init()
+    sc = scenes.cornell_box()
+    pages = scenes.lightmap_pages_for(sc, S, tpu, max_pages=3)
+    assert len(pages) >= 1
+    pages = [p.copy() for p in pages] + [pages[0].copy()]
+    pages[-1][S * S * 26:] = 0                                            # the last page: nothing mapped
+    pg = [p.copy() for p in pages]
+    po = [p.copy() for p in pages]
+    g = api.Scene(sc.desc)
+    o = OracleScene(sc.desc, accel=1)
+    total = len(pages) * S * S
+    calls = [(1.0, 2, 0, 0, -1), (1.0, 1, 1, 0, 0), (1.0, 1, 2, total // 3, total // 3), (1.0, 2, 3, max(0, S * S - 1), min(total, S * S + 2)),
+             (0.01, 1, 4, 0, -1), (0.5, 3, 5, total - 1, total)]
+    for slice_, spp, passIndex, begin, end in calls:
+        g.lightmap_bake(pg, S, tpu, slice_, spp, passIndex=passIndex, seed=5, maxBounces=3, texelBegin=begin, texelEnd=end)
+        o.lightmap_bake(po, S, tpu, slice_, spp, passIndex=passIndex, seed=5, maxBounces=3, texelBegin=begin, texelEnd=end)
+        for k, (a, b) in enumerate(zip(pg, po)):
+            assert_bits_equal(a, b, f"page {k} after call {passIndex}")
+    g.close()
