@@ -1378,7 +1378,7 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         if (hipMalloc(&b->cnodes, sizeof(uint4) * 4 * (size_t)cap) != hipSuccess) return PIMGPU_E_NOMEM;
         if (hipMalloc(&b->tris, sizeof(float4) * 3 * ((size_t)cap + 1)) != hipSuccess) return PIMGPU_E_NOMEM;     /* + 1: traverse.h reads 64 B of a one-triangle leaf */
         if (hipMalloc(&b->scratch, need) != hipSuccess) return PIMGPU_E_NOMEM;
-        if (hipHostMalloc((void**)&b->progress, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return PIMGPU_E_NOMEM;
+        if (hipHostMalloc((void**)&b->progress, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return PIMGPU_E_NOMEM;
         b->capacityTris = cap; b->scratchBytes = need;
     }
     char* s = (char*)b->scratch;
