@@ -1517,8 +1517,8 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
         rootId = &ploc->rootId;
     }
     if (!orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, order, n, b->tris);
-    /* collapse, level by level; the level count is only known on the device, so levels go out in batches of 8
-     * and the level table is read back after each batch (one short sync per batch, 2-3 for a million triangles) */
+    /* collapse, level by level; the level count is only known on the device, so levels go out in batches (the first about
+     * log2 n long, then 8 at a time) and the level table is read back after each batch: one short sync per batch, usually one */
     if (packed) k_collapse_begin_p<<<1, 64, 0, stream>>>(snap, wideSrc, wideFirst, rootId);          /* snap[]: nodes per level here */
     else k_collapse_begin<<<1, 64, 0, stream>>>(snap, nodeCounter, wideSrc, wideFirst, rootId);
     int32_t hostSnap[kMaxWideLevels + 2];
