@@ -1570,6 +1570,8 @@ int bvh_build(BvhStorage* b, const v4* positionsDev, int32_t triCount, hipStream
             if (hostSnap[l + 1] == hostSnap[l]) { done = true; b->depth = l; b->nodeCount = hostSnap[l]; break; }
         }
     }
+    /* the batched traversal kernels address a node by a 32-bit byte offset from the array's base (one shift, the base in scalar registers) */
+    if ((int64_t)b->nodeCount >= (1ll << 26)) { set_error("BVH build: %d wide nodes; the traversal kernels take fewer than 2^26", b->nodeCount); return PIMGPU_E_LIMIT; }
     if (orderInCollapse) k_emit_tris<<<grid, 256, 0, stream>>>(positionsDev, vals2, n, b->tris);     /* the collapse has written the triangles' order */
     k_compress_nodes<<<(b->nodeCount + 255) / 256, 256, 0, stream>>>(b->nodes, b->nodeCount, b->cnodes);
     return hipGetLastError() == hipSuccess ? PIMGPU_OK : PIMGPU_E_DEVICE;

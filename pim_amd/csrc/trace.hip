@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kTraceThreads, PT_TRACE_WAVES) void k_trace(DBvh bv
             if (active && cur >= 0)
             {
                 if (COUNT) { ++cNodes; ++rayNodes; }
-                const uint4* q = cnodes + (size_t)cur * 4;
+                const uint4* q = (const uint4*)((const char*)cnodes + ((uint32_t)cur << 6));       /* a 32-bit offset from a uniform base (trees below 2^26 nodes: bvh_build checks) */
                 const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
                 float d[4]; int32_t c[4];
                 c[0] = (int32_t)w3.x; c[1] = (int32_t)w3.y; c[2] = (int32_t)w3.z; c[3] = (int32_t)w3.w;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kTraceThreads, COUNT ? 1 : PT_TRACEQ_WAVES) void k_
             if (active && cur >= 0)
             {
                 if (COUNT) { ++cNodes; ++rayNodes; }
-                const uint4* q = cnodes + (size_t)cur * 4;
+                const uint4* q = (const uint4*)((const char*)cnodes + ((uint32_t)cur << 6));       /* 32-bit offset from a uniform base, as in k_trace */
                 const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
                 const float lim = __uint_as_float((uint32_t)(best[laneBase + lane] >> 32));
                 float d[4]; int32_t c[4];
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kTraceThreads, COUNT ? 1 : PT_TRACEQ_WAVES) void k_
                     if (mine)
                     {
                         if (COUNT) ++cTris;
-                        const float4* tp = tris + (size_t)(e & ((1u << kQueueTriBits) - 1u)) * 3;
+                        const float4* tp = (const float4*)((const char*)tris + (e & ((1u << kQueueTriBits) - 1u)) * 48u);      /* < 2^26 triangles here (trace_queue_ok): the byte offset fits 32 bits */
                         const float4 p0 = tp[0], p1 = tp[1], p2 = tp[2];
                         const float lim = __uint_as_float((uint32_t)(best[laneBase + owner] >> 32));
                         float t;
