@@ -1344,6 +1344,13 @@ static const int kTailWavesPerCu = env_int("PIMGPU_TAIL_WAVES", 0);           /*
  * 1 M triangles: 3.42 / 3.10 / 3.13 ms at 3 / 4 / 5).  The host picks by the size of the tree. */
 static constexpr int64_t kTailDenseTreeBytes = 8ll << 20;
 
+/* the previous call's queue length at bounce b, for a call of n paths: the same image cut differently (the shares of
+ * pimgpu_trace_image_host change size from one call to the next) keeps its proportions, so a history of another size within a
+ * factor of two is scaled rather than dropped.  Sizes of launches and the switch to the tail kernel come from it, no result does. */
+static bool history_fits(const PathGroup& g, int64_t n) { return g.historyBounces > 0 && g.historyN > 0 && n <= 2 * g.historyN && 2 * n >= g.historyN; }
+static int64_t history_at(const PathGroup& g, int64_t n, int32_t b)
+{ return g.historyN == n ? (int64_t)g.history[b] : (int64_t)((double)g.history[b] * (double)n / (double)g.historyN); }
+
 static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
 {
     if (const char* e = getenv("PIMGPU_TAIL_BOUNCE")) { const int v = atoi(e); return v < 0 ? bounceLimit : std::min(v, bounceLimit); }
@@ -1354,9 +1361,9 @@ static int32_t tail_policy(const PathGroup& g, int32_t n, int32_t bounceLimit)
      * Knobs, not API: the threshold in paths and a divisor of the batch size (off = 1). */
     const int64_t threshold = std::min<int64_t>((int64_t)n / std::max(1, env_int("PIMGPU_TAIL_FRACTION", 1)), std::max(1, env_int("PIMGPU_TAIL_MAX_PATHS", 2500000)));
     if ((int64_t)n <= threshold) return 0;
-    if (g.historyN != n || g.historyBounces <= 0) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
+    if (!history_fits(g, n)) return bounceLimit == 666 ? 16 : bounceLimit;     /* no history yet */
     for (int32_t b = 1; b < g.historyBounces && b < bounceLimit; ++b)
-        if ((int64_t)g.history[b] < threshold) return b;
+        if (history_at(g, n, b) < threshold) return b;
     return bounceLimit == 666 ? std::max(16, g.historyBounces) : bounceLimit;
 }
 
@@ -1430,7 +1437,7 @@ int Library::ensure_group(int gi)
 
 void Library::release_groups()
 {
-    if (frameBegin) { hipEventDestroy(frameBegin); hipEventDestroy(frameEnd); frameBegin = frameEnd = nullptr; }
+    if (frameBegin) { hipEventDestroy(frameBegin); hipEventDestroy(frameEnd); if (copyBegin) hipEventDestroy(copyBegin); if (copyEnd) hipEventDestroy(copyEnd); frameBegin = frameEnd = copyBegin = copyEnd = nullptr; }
     for (int gi = 0; gi < kMaxGroups; ++gi)
     {
         PathGroup& g = groups[gi];
@@ -1486,7 +1493,7 @@ static int integrate_enqueue(PimScene* scene, PathGroup& g, int32_t first, int32
     {
         /* One lane per path of the expected queue (the previous call's length at this bounce), but no more waves than
          * the machine holds at k_tail's occupancy: lanes take further paths as theirs end */
-        const int64_t expect = mainEmpty ? std::max<int64_t>(4096, n / 64) : ((g.historyN == n && b < g.historyBounces) ? (int64_t)g.history[b] : (int64_t)n);
+        const int64_t expect = mainEmpty ? std::max<int64_t>(4096, n / 64) : ((history_fits(g, n) && b < g.historyBounces) ? std::min<int64_t>(n, history_at(g, n, b)) : (int64_t)n);
         a.tailLanes = std::max(1, std::min(64, env_int("PIMGPU_TAIL_LANES", 64)));
         a.tailMainEmpty = mainEmpty ? 1 : 0;
         const int64_t treeBytes = 64ll * scene->d.bvh.nodeCount + 48ll * scene->d.bvh.triCount;
@@ -1567,7 +1574,12 @@ static int integrate_finish(PathGroup& g, PimTraceStats* statsOut, float* traceM
     if (hs[4] & 1ull) { set_error("path tracing: traversal stack overflow (tree deeper than %d entries)", PT_STACK_MAX); return PIMGPU_E_LIMIT; }
     /* queue lengths of the wavefront bounces of this call: the next call's tail policy.  A call that switched early keeps
      * what the history knew beyond its switch point. */
-    if (g.historyN != g.n) { g.historyN = g.n; g.historyBounces = 0; }
+    if (g.historyN != g.n)
+    {
+        if (history_fits(g, g.n)) { for (int32_t b = 0; b < g.historyBounces; ++b) g.history[b] = (int32_t)history_at(g, g.n, b); }     /* another cut of the same image */
+        else g.historyBounces = 0;
+        g.historyN = g.n;
+    }
     for (int32_t b = 0; b < g.wavefrontBounces && b < PT_COUNTS_MAX; ++b) g.history[b] = counts[PT_COUNTS_BASE + b];
     g.historyBounces = std::max(g.historyBounces, std::min<int32_t>(g.wavefrontBounces, PT_COUNTS_MAX));
     if (statsOut)
@@ -1739,7 +1751,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     hipStream_t st = g_lib.stream;
     WorkBuffers& w = g_lib.work;
     if ((rc = w.ensure_paths(n))) return rc;
-    if (!g_lib.frameBegin) { PT_HIP(hipEventCreate(&g_lib.frameBegin)); PT_HIP(hipEventCreate(&g_lib.frameEnd)); }
+    if (!g_lib.frameBegin) { PT_HIP(hipEventCreate(&g_lib.frameBegin)); PT_HIP(hipEventCreate(&g_lib.frameEnd)); PT_HIP(hipEventCreate(&g_lib.copyBegin)); PT_HIP(hipEventCreate(&g_lib.copyEnd)); }
     hipEvent_t e0 = g_lib.frameBegin, e1 = g_lib.frameEnd;
     PT_HIP(hipEventRecord(e0, st));
     if (p->updateDists && !distsDone) { if ((rc = update_dists(scene->d, st))) return rc; }      /* PtScene_Update, pt.c:1034 */
@@ -1770,6 +1782,7 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     c.pixelBegin = pixelBegin; c.pixelCount = n; c.slotBegin = 0;
     PimTraceStats stats; memset(&stats, 0, sizeof(stats));
     float traceMs = 0.0f;
+    int32_t copyPixels = 0;                                                       /* pixels of the share whose copies copyEnd follows */
     const bool toHost = hostColor || hostAlbedo || hostNormal;
     /* shares of at least 256 k pixels, 2 by default (PIMGPU_HOST_SHARES; measured at 1080p, 1 / 2 / 4 / 8 shares: 3.17 / 2.80 / 3.27 /
      * 4.29 ms per call -- every share's launch ends with its own slowest waves) */
@@ -1780,10 +1793,22 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     {
         const bool timeTrace = p->updateDists >= 0 && !getenv("PIMGPU_NO_EVENTS");
         for (int k = 0; k < shares; ++k) if ((rc = g_lib.ensure_group(k))) return rc;
-        /* the first share is the larger one (PIMGPU_HOST_FIRST eighths of its equal part, default 10 = 5/4): the copy that is left
-         * over at the end is the LAST share's */
-        const int32_t firstEighths = std::max(1, std::min(8 * shares - 1, env_int("PIMGPU_HOST_FIRST", 10)));
-        const int32_t firstCount = (int32_t)(((int64_t)n * firstEighths / (8 * shares) + 63) & ~(int64_t)63);
+        /* the first share is the larger one: the copy that is left over at the end is the LAST share's.  With t the time to trace a
+         * pixel and c the time to copy one home, the first share's copy hides behind the second share's tracing up to the fraction
+         * f = t / (t + c) of the pixels; both are measured on this PtTrace's previous call (c from the last share's copies, so a
+         * pageable host image shows as the slower copy it is), and the smaller second launch traces a little slower per pixel, which
+         * moves the measured optimum up by 0.02 ("Pt_Trace through the host layer").  PIMGPU_HOST_FIRST
+         * (eighths of an equal part) sets the size by hand; without history it is 10 = 5/4 of an equal part. */
+        int64_t firstWant = (int64_t)n * 10 / (8 * shares);
+        if (getenv("PIMGPU_HOST_FIRST")) firstWant = (int64_t)n * std::max(1, std::min(8 * shares - 1, env_int("PIMGPU_HOST_FIRST", 10))) / (8 * shares);
+        else if (shares == 2 && t->hostTraceNs > 0.0f && t->hostCopyNs > 0.0f)
+        {
+            firstWant = (int64_t)((double)n * std::min(0.875, std::max(0.5, (double)t->hostTraceNs / ((double)t->hostTraceNs + (double)t->hostCopyNs) + 0.02)));
+            /* within 3 % of the previous call's size: that one again (the launches' sizes follow the previous call's queue lengths) */
+            if (t->hostN == n && std::abs(firstWant - (int64_t)t->hostFirst) * 100 < 3 * (int64_t)n) firstWant = t->hostFirst;
+        }
+        const int32_t firstCount = (int32_t)std::min<int64_t>(n, (firstWant + 63) & ~(int64_t)63);
+        t->hostN = n; t->hostFirst = firstCount;
         const int32_t per = shares > 1 ? (int32_t)((((int64_t)(n - firstCount) + shares - 2) / (shares - 1) + 63) & ~(int64_t)63) : n;
         int used = 0;
         for (int k = 0; k < shares && rc == PIMGPU_OK; ++k)
@@ -1805,10 +1830,12 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
             if (hipEventRecord(g.done, s) != hipSuccess) { set_error("trace_image: hipEventRecord failed"); rc = PIMGPU_E_DEVICE; break; }
             if (last) hipEventRecord(e1, s);
             /* this share's pixels go home while the next share is traced */
+            if (k == 0 && timeTrace) hipEventRecord(g_lib.copyBegin, s);
             const size_t off = (size_t)(pixelBegin + first) * 3, bytes = sizeof(float) * 3 * (size_t)count;
             if (hostColor) hipMemcpyAsync(hostColor + off, t->color + off, bytes, hipMemcpyDeviceToHost, s);
             if (hostAlbedo) hipMemcpyAsync(hostAlbedo + off, t->albedo + off, bytes, hipMemcpyDeviceToHost, s);
             if (hostNormal) hipMemcpyAsync(hostNormal + off, t->normal + off, bytes, hipMemcpyDeviceToHost, s);
+            if (k == 0 && timeTrace) { hipEventRecord(g_lib.copyEnd, s); copyPixels = count; }
         }
         for (int k = used - 1; k >= 0; --k)
         {
@@ -1840,6 +1867,17 @@ static int trace_image_one(PimScene* scene, PimTrace* t, const PimCamera* cam, P
     stats.otherRays += otherRays;
     stats.traceMs = traceMs; stats.totalMs = totalMs;
     t->stats = stats;
+    if (copyPixels > 0)                                                            /* what the next call sizes its first share with */
+    {
+        float copyMs = 0.0f;
+        if (hipEventElapsedTime(&copyMs, g_lib.copyBegin, g_lib.copyEnd) == hipSuccess && copyMs > 0.0f && totalMs > 0.0f)
+        {
+            const float tn = totalMs * 1e6f / (float)n, cn = copyMs * 1e6f / (float)copyPixels;
+            t->hostTraceNs = t->hostTraceNs > 0.0f ? 0.5f * (t->hostTraceNs + tn) : tn;
+            t->hostCopyNs = t->hostCopyNs > 0.0f ? 0.5f * (t->hostCopyNs + cn) : cn;
+        }
+        if (getenv("PIMGPU_HOST_LOG")) fprintf(stderr, "host: total %.3f ms copy %.3f ms of %d px of %d -> t %.3f c %.3f ns\n", totalMs, copyMs, copyPixels, n, t->hostTraceNs, t->hostCopyNs);
+    }
     return PIMGPU_OK;
 }
 

@@ -48,6 +48,9 @@ struct PimTrace
      * and on context 0 the landing place of the other contexts' means on their way into the sum */
     PimTrace* sampleAcc = nullptr;
     PimTrace* sampleStage = nullptr;
+    /* pimgpu_trace_image_host: ns per pixel of tracing and of the copy home on the previous call (0: no call yet) */
+    float hostTraceNs = 0.0f, hostCopyNs = 0.0f;
+    int32_t hostN = 0, hostFirst = 0;    /* ... and that call's pixels and first share */
 };
 
 namespace pt {
@@ -125,6 +128,7 @@ struct Library
     TraceResources trace;
     WorkBuffers work;
     hipEvent_t frameBegin = nullptr, frameEnd = nullptr;     /* pimgpu_trace_image's totalMs */
+    hipEvent_t copyBegin = nullptr, copyEnd = nullptr;       /* around the first share's copies home (pimgpu_trace_image_host) */
     float* smallBack = nullptr;                              /* 64 page-locked bytes made at init: where pimgpu_trace_stddev_noalloc's two floats land (a copy
                                                                 into pageable memory is staged by the runtime, which may allocate) */
     PathGroup groups[kMaxGroups];
