@@ -327,7 +327,22 @@ void* pimgpu_host_alloc(size_t bytes)
 {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error("host_alloc: %zu bytes of page-locked memory", bytes); return nullptr; }
-    memset(p, 0, bytes);
+    /* zeroed like the Tex_Calloc it stands for; a lightmap page is 113 MB and a pack has dozens: several threads clear a large block
+     * (the first touch of page-locked memory is cheap, the pages are there; one core's store rate is the limit) */
+    const size_t kPart = (size_t)16 << 20;
+    const unsigned workers = (unsigned)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), bytes / kPart);
+    if (workers <= 1) memset(p, 0, bytes);
+    else
+    {
+        std::vector<std::thread> pool;
+        const size_t per = ((bytes + workers - 1) / workers + 4095) & ~(size_t)4095;
+        for (unsigned k = 0; k < workers; ++k)
+        {
+            const size_t lo = std::min(bytes, per * k), hi = std::min(bytes, per * (k + 1));
+            if (hi > lo) pool.emplace_back([=] { memset((char*)p + lo, 0, hi - lo); });
+        }
+        for (auto& t : pool) t.join();
+    }
     return p;
 }
 

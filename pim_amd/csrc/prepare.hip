@@ -458,91 +458,254 @@ __global__ __launch_bounds__(kAtlasThreads) void k_atlas_place(AtlasArgs a)
  * one bit; an atlas of up to 1024^2 texels -- the size the reference packs (render_system.c:176) -- is 128 KiB and fits the
  * CU's 160 KiB of LDS beside the chart's own mask (as bit rows, <= kItemWordsLds 64-bit words; a larger one stays in HBM).
  * A candidate translation is then tested row by row with 64 texels per AND, on LDS words every lane of a wave shares
- * (broadcast reads), instead of byte by byte through the vector L1: 27 -> ~3 us per chart.  The atlas in LDS is written
- * back to HBM (atlasBits) only when the search moves to another atlas.
+ * (broadcast reads), instead of byte by byte through the vector L1.  The atlas in LDS is written back to HBM (atlasBits) only
+ * when the search moves to another atlas and something was placed in it.
+ *
+ * The chain from one chart to the next is what the kernel's time is made of, so everything that is not the search is taken off it:
+ *   - the charts' descriptors and bit rows are laid out in PLACEMENT order by a parallel pass before (k_chart_bits); the loop
+ *     reads the descriptor two charts ahead and the bit rows one chart ahead, into the other half of the item buffer, so no
+ *     load from HBM is waited for between two charts;
+ *   - a round of the scan costs ONE barrier (three result slots in rotation: the slot of round r + 1 is cleared during round r);
+ *   - a lane keeps its column x and walks down rows (no division per candidate); a wave reports its first fitting lane by a
+ *     ballot, one LDS atomic per wave instead of one per fitting lane;
+ *   - a round that finds nothing doubles the rows of the next one (up to 16 per lane): the long scans through crowded atlases
+ *     after a reset of the hints pay a sixteenth of the barriers.
+ * The candidates are the reference's, in its order (row-major from the starting row), and the lowest fitting one wins.
  */
 static constexpr int kAtlasBitsMaxSize = 1024;
 static constexpr int kAtlasRowWordsMax = kAtlasBitsMaxSize / 64;
 static constexpr int kItemWordsLds = 3584;                     /* 28 KiB: a 345 x 345 chart (a third of the atlas + margins) has 2070 */
+static constexpr int kAtlasBitThreads = 256;                   /* one wave per SIMD: the chain from chart to chart is barriers and issue slots, not lanes */
+static constexpr int kItemWordsSmall = kAtlasBitThreads;       /* a chart of at most a word per lane: prefetched, two of them side by side */
+static constexpr int kAtlasRowsMax = 16;                       /* rows of candidates per lane and round, at most */
+struct ChartDesc { int32_t bw, bh; float area; uint32_t wordOff; };      /* in placement order */
 struct AtlasBitArgs
 {
-    AtlasArgs a;
+    AtlasArgs a;                        /* translations / atlasIndex / status[0] are in placement order here (the host maps them back) */
     unsigned long long* atlasBits;      /* [atlasCap][S * rowWords]: atlases not in LDS at the moment; zeroed by the host */
-    unsigned long long* itemBits;       /* [S * rowWords]: bit rows of a chart too large for LDS */
+    const ChartDesc* desc;              /* [chartCount] */
+    const unsigned long long* bits;     /* the charts' bit rows, chart i's at desc[i].wordOff */
 };
 
-__global__ __launch_bounds__(kAtlasThreads) void k_atlas_place_bits(AtlasBitArgs g)
+/* a wave per chart: the mask's bytes as rows of 64-bit words */
+__global__ __launch_bounds__(256) void k_chart_bits(const uint8_t* __restrict__ masks, const int64_t* __restrict__ maskOffsets, const int32_t* __restrict__ order,
+    const ChartDesc* __restrict__ desc, int32_t chartCount, unsigned long long* __restrict__ bits)
+{
+    const int32_t i = (int32_t)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = (int32_t)(threadIdx.x & 63);
+    if (i >= chartCount) return;
+    const ChartDesc d = desc[i];
+    const uint8_t* __restrict__ item = masks + maskOffsets[order[i]];
+    const int32_t rowWords = (d.bw + 63) >> 6, words = d.bh * rowWords;
+    for (int32_t w = lane; w < words; w += 64)
+    {
+        const int32_t by = w / rowWords, x0 = (w % rowWords) * 64;
+        const uint8_t* brow = item + (size_t)by * (size_t)d.bw;
+        unsigned long long v = 0ull;
+        const int32_t n = min(64, d.bw - x0);
+        for (int32_t b = 0; b < n; ++b) if (brow[x0 + b]) v |= 1ull << b;
+        bits[(size_t)d.wordOff + (size_t)w] = v;
+    }
+}
+
+/* OR over each row of 16 lanes, in every lane of the row (four rotations within the row: vector instructions, no LDS crossbar) */
+__device__ __forceinline__ uint32_t row16_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);          /* row_ror:1 */
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);          /* row_ror:2 */
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);          /* row_ror:4 */
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);          /* row_ror:8 */
+    return v;
+}
+
+__global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitArgs g)
 {
     const AtlasArgs& a = g.a;
     __shared__ unsigned long long sAtlas[kAtlasBitsMaxSize * kAtlasRowWordsMax];
     __shared__ unsigned long long sItem[kItemWordsLds];
-    __shared__ int32_t sBest;
+    __shared__ int32_t sBest[4];
     const int32_t tid = (int32_t)threadIdx.x;
     const int32_t S = a.atlasSize;
     const int32_t rowWords = (S + 63) >> 6;
     const int32_t atlasWords = S * rowWords;
+    const int32_t n = a.chartCount;
     int32_t prevAtlas = 0, prevRow = PT_ROW_RESET;
     float prevArea = (float)(1 << 23);
     int32_t atlasCount = a.atlasCount;
     int32_t resident = -1;                                      /* the atlas whose bits are in LDS */
-    for (int32_t i = 0; i < a.chartCount; ++i)
+    bool dirty = false;                                         /* ... and whether it differs from its copy in HBM */
+    uint32_t round = 0;                                         /* rounds of the scan so far: the result slot in use is round % 3 */
+    int32_t swaps = 0;
+    if (tid < 3) sBest[tid] = 0x7fffffff;
+    int32_t opaqueZero;                                         /* 0, in a vector register the compiler knows nothing about */
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaqueZero));
+    ChartDesc cur = g.desc[0], nxt = g.desc[min(1, n - 1)];
+    int32_t half = 0;                                           /* which half of sItem holds a small chart's rows */
     {
-        const int32_t c = a.order[i];
-        const uint8_t* __restrict__ item = a.masks + a.maskOffsets[c];
-        const int32_t bw = a.maskSizes[2 * c], bh = a.maskSizes[2 * c + 1];
-        const float area = a.areas[c];
-        if (area < (prevArea * 0.9f)) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
-        /* the chart's mask as bit rows */
+        const int32_t words = cur.bh * ((cur.bw + 63) >> 6);
+        if (words <= kItemWordsLds) for (int32_t w = tid; w < words; w += kAtlasBitThreads) sItem[w] = g.bits[(size_t)cur.wordOff + w];
+    }
+    __syncthreads();
+    for (int32_t i = 0; i < n; ++i)
+    {
+        /* the descriptor two charts ahead, as a VECTOR load whose result is made uniform only at the end of this chart's
+         * placement: a uniform load is waited for where it is issued (its readfirstlane follows at once), and that wait is a
+         * trip to L2 or HBM on the chain from chart to chart */
+        const int4 aheadV = ((const int4*)g.desc)[min(i + 2, n - 1) + opaqueZero];
+        const int32_t bw = cur.bw, bh = cur.bh;
+        const float area = cur.area;
         const int32_t itemRowWords = (bw + 63) >> 6;
         const int32_t itemWords = bh * itemRowWords;
         const bool itemInLds = itemWords <= kItemWordsLds;
-        for (int32_t w = tid; w < itemWords; w += kAtlasThreads)
-        {
-            const int32_t by = w / itemRowWords, x0 = (w % itemRowWords) * 64;
-            const uint8_t* brow = item + (size_t)by * (size_t)bw;
-            unsigned long long bits = 0ull;
-            const int32_t n = min(64, bw - x0);
-            for (int32_t b = 0; b < n; ++b) if (brow[x0 + b]) bits |= 1ull << b;
-            if (itemInLds) sItem[w] = bits; else g.itemBits[w] = bits;
-        }
-        if (!itemInLds) __threadfence();
-        __syncthreads();
+        const bool small = itemWords <= kItemWordsSmall;
+        const unsigned long long* __restrict__ itemHbm = g.bits + (size_t)cur.wordOff;
+        const unsigned long long* item = sItem + (small ? half * kItemWordsSmall : 0);
+        /* the next chart's rows: on their way while this one is placed */
+        const int32_t nextWords = nxt.bh * ((nxt.bw + 63) >> 6);
+        const bool nextSmall = i + 1 < n && nextWords <= kItemWordsSmall;
+        unsigned long long pre = 0ull;
+        if (nextSmall && tid < nextWords) pre = g.bits[(size_t)nxt.wordOff + tid];
+        if (area < (prevArea * 0.9f)) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
         bool placed = false;
         for (int attempt = 0; attempt < 3 && !placed; ++attempt)
         {
             for (int32_t at = prevAtlas; at < atlasCount && !placed; ++at)
             {
-                if (resident != at)
-                {
-                    /* swap the LDS atlas: write the resident one back, bring this one in */
-                    if (resident >= 0) for (int32_t w = tid; w < atlasWords; w += kAtlasThreads) g.atlasBits[(size_t)resident * atlasWords + w] = sAtlas[w];
-                    __threadfence();
-                    __syncthreads();
-                    for (int32_t w = tid; w < atlasWords; w += kAtlasThreads) sAtlas[w] = g.atlasBits[(size_t)at * atlasWords + w];
-                    resident = at;
-                    __syncthreads();
-                }
                 const int32_t rangeX = S - bw, rangeY = S - bh;
                 const int32_t y0 = (prevRow != PT_ROW_RESET) ? prevRow : 0;
-                int64_t found = -1;
+                int32_t foundX = -1, foundY = -1;
                 if (rangeX > 0 && rangeY > y0)
                 {
-                    const int64_t total = (int64_t)(rangeY - y0) * rangeX;
-                    for (int64_t base = 0; base < total && found < 0; base += kAtlasThreads)
+                    if (resident != at)
                     {
-                        if (tid == 0) sBest = 0x7fffffff;
+                        /* swap the LDS atlas: write the resident one back, bring this one in */
+                        if (resident >= 0 && dirty) for (int32_t w = tid; w < atlasWords; w += kAtlasBitThreads) g.atlasBits[(size_t)resident * atlasWords + w] = sAtlas[w];
+                        __threadfence();
                         __syncthreads();
-                        const int64_t idx = base + tid;
-                        if (idx < total)
+                        for (int32_t w = tid; w < atlasWords; w += kAtlasBitThreads) sAtlas[w] = g.atlasBits[(size_t)at * atlasWords + w];
+                        resident = at; dirty = false; ++swaps;
+                        __syncthreads();
+                    }
+                    if (itemRowWords == 1 && bh <= 64)
+                    {
+                        /* A mask of at most 64 x 64 texels (nearly every chart): the test runs over WORDS of candidates.  Wave w
+                         * owns the columns 64 w .. 64 w + 63 of a candidate row y; its lane `by` takes row `by` of the mask and
+                         * forms, for all 64 columns at once, where that row collides: the OR over the mask row's set bits b of
+                         * (atlas row y + by) >> b -- run by run, a run of L bits in log2 L shift-ORs.  The OR over the lanes is
+                         * the blocked columns of row y; the first clear bit is the first fit.  Masks of up to 16 (32) rows share
+                         * a wave four (two) candidate rows at a time. */
+                        const int32_t G = bh <= 16 ? 16 : (bh <= 32 ? 32 : 64), perWave = 64 / G;
+                        const int32_t lane = tid & 63, wave = tid >> 6;
+                        const int32_t gi = lane / G, by = lane & (G - 1);
+                        /* a unit of work = (candidate row j, word w of columns), numbered u = 16 j + w in candidate order; a group of
+                         * G lanes takes one unit, groups in unit order over the waves: a round of ONE candidate row (nine in ten) keeps
+                         * 16 / perWave waves busy, one per SIMD when masks have <= 16 rows, and the others step aside */
+                        const unsigned long long iw = by < bh ? item[by] : 0ull;
+                        int32_t rows = 1;                                            /* candidate rows in the next round */
+                        for (int32_t yBase = y0; yBase < rangeY && foundY < 0; )
                         {
-                            const int32_t y = y0 + (int32_t)(idx / rangeX), x = (int32_t)(idx % rangeX);
-                            bool fits = true;
+                            const uint32_t slot = round % 3u;
+                            if (tid == 0) sBest[(round + 1u) % 3u] = 0x7fffffff;
+                            const int32_t units = rows * 16;
+                            for (int32_t u0 = wave * perWave; u0 < units; u0 += (kAtlasBitThreads / 64) * perWave)
+                            {
+                                const int32_t u = u0 + gi;
+                                const int32_t rowOff = u >> 4, w = u & 15;
+                                const int32_t y = yBase + rowOff;
+                                const bool live = rowOff < rows && y < rangeY && w < rowWords;
+                                unsigned long long B = 0ull;
+                                if (live && iw)
+                                {
+                                    const unsigned long long* arow = sAtlas + (y + by) * rowWords;
+                                    const unsigned long long A0 = arow[w], A1 = (w + 1 < rowWords) ? arow[w + 1] : 0ull;
+                                    unsigned long long m = iw;
+                                    while (m)
+                                    {
+                                        const int32_t l = __builtin_ctzll(m);
+                                        const unsigned long long run = ~(m >> l);
+                                        const int32_t L = run ? __builtin_ctzll(run) : 64;               /* l + L <= 64 */
+                                        m = (l + L >= 64) ? 0ull : (m & (~0ull << (l + L)));
+                                        unsigned long long U0 = (A0 >> l) | (l ? (A1 << (64 - l)) : 0ull), U1 = A1 >> l;
+                                        for (int32_t k = 1; k < L; )
+                                        {
+                                            const int32_t sft = min(k, L - k);
+                                            U0 |= (U0 >> sft) | (U1 << (64 - sft)); U1 |= U1 >> sft;
+                                            k += sft;
+                                        }
+                                        B |= U0;
+                                    }
+                                }
+                                {
+                                    uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
+                                    B = ((unsigned long long)hi << 32) | lo;
+                                    if (G >= 32) B |= __shfl_xor(B, 16);
+                                    if (G == 64) B |= __shfl_xor(B, 32);
+                                }
+                                const int32_t nvalid = rangeX - 64 * w;
+                                const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
+                                const unsigned long long open = live ? (~B & validMask) : 0ull;
+                                const unsigned long long vote = __ballot(by == 0 && open != 0ull);
+                                if (vote)                                            /* groups of a wave are in candidate order */
+                                {
+                                    if (lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], rowOff * 1024 + 64 * w + __builtin_ctzll(open));
+                                    break;
+                                }
+                            }
+                            __syncthreads();
+                            const int32_t best = sBest[slot];
+                            ++round;
+                            if (best != 0x7fffffff) { foundY = yBase + (best >> 10); foundX = best & 1023; }
+                            else { yBase += rows; rows = min(64, rows * 2); }
+                        }
+                    }
+                    else
+                    {
+                    /* lane -> (row within a pass, column): several rows per pass when the lanes outnumber the columns, several
+                     * passes per row when the columns outnumber the lanes */
+                    const int32_t rowsPer = max(1, kAtlasBitThreads / rangeX);
+                    const int32_t lr = rowsPer > 1 ? tid / rangeX : 0, x0 = tid - lr * rangeX;
+                    const bool active = lr < rowsPer;
+                    int32_t rows = 1;                                                /* passes per lane in the next round */
+                    for (int32_t yBase = y0; yBase < rangeY && foundY < 0; )
+                    {
+                        const uint32_t slot = round % 3u;
+                        if (tid == 0) sBest[(round + 1u) % 3u] = 0x7fffffff;
+                        bool voted = false;
+                        for (int32_t j = 0; j < rows && !voted; ++j)
+                        for (int32_t xb = 0; xb < rangeX && !voted; xb += kAtlasBitThreads)
+                        {
+                            const int32_t rowOff = j * rowsPer + lr, x = x0 + xb;
+                            const int32_t y = yBase + rowOff;
+                            bool fits = active && x < rangeX && y < rangeY;
+                            if (itemRowWords == 1)
+                            {
+                                /* a mask of at most 64 columns (nearly every chart): four rows per step, their reads independent of
+                                 * each other -- row by row the test is a chain of LDS latencies */
+                                const int32_t wi = x >> 6, sh = x & 63;
+                                const bool two = sh != 0 && wi + 1 < rowWords;
+                                const int32_t wj = two ? wi + 1 : wi;
+                                const int32_t shUp = two ? 64 - sh : 0;
+                                const unsigned long long keepUp = two ? ~0ull : 0ull;
+                                for (int32_t by = 0; by < bh && fits; by += 4)
+                                {
+                                    unsigned long long hit = 0ull;
+#pragma unroll
+                                    for (int32_t u = 0; u < 4; ++u)
+                                    {
+                                        const int32_t r = min(by + u, bh - 1);
+                                        const unsigned long long* arow = sAtlas + (y + r) * rowWords;
+                                        const unsigned long long aw = (arow[wi] >> sh) | ((arow[wj] << shUp) & keepUp);
+                                        hit |= aw & item[r];
+                                    }
+                                    if (hit) fits = false;
+                                }
+                            }
+                            else
                             for (int32_t by = 0; by < bh && fits; ++by)
                             {
                                 const unsigned long long* arow = sAtlas + (y + by) * rowWords;
                                 for (int32_t k = 0; k < itemRowWords; ++k)
                                 {
-                                    const unsigned long long iw = itemInLds ? sItem[by * itemRowWords + k] : g.itemBits[by * itemRowWords + k];
+                                    const unsigned long long iw = itemInLds ? item[by * itemRowWords + k] : itemHbm[by * itemRowWords + k];
                                     if (!iw) continue;
                                     const int32_t pos = x + 64 * k, wi = pos >> 6, sh = pos & 63;
                                     unsigned long long aw = arow[wi] >> sh;
@@ -550,28 +713,36 @@ __global__ __launch_bounds__(kAtlasThreads) void k_atlas_place_bits(AtlasBitArgs
                                     if (aw & iw) { fits = false; break; }
                                 }
                             }
-                            if (fits) atomicMin(&sBest, tid);
+                            const unsigned long long vote = __ballot(fits);
+                            if (vote)                                                /* lanes of a wave are in candidate order, and pass j before pass j + 1 */
+                            {
+                                if ((int32_t)(threadIdx.x & 63) == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], rowOff * 1024 + x);
+                                voted = true;
+                            }
                         }
                         __syncthreads();
-                        const int32_t best = sBest;
-                        __syncthreads();
-                        if (best != 0x7fffffff) found = base + best;
+                        const int32_t best = sBest[slot];
+                        ++round;
+                        if (best != 0x7fffffff) { foundY = yBase + (best >> 10); foundX = best & 1023; }
+                        else { yBase += rows * rowsPer; rows = min(kAtlasRowsMax, rows * 2); }
+                    }
                     }
                 }
-                if (found >= 0)
+                if (foundY >= 0)
                 {
-                    const int32_t ty = y0 + (int32_t)(found / rangeX), tx = (int32_t)(found % rangeX);
-                    for (int32_t w = tid; w < itemWords; w += kAtlasThreads)                 /* mask_write, lightmap.c:209-230 */
+                    const int32_t ty = foundY, tx = foundX;
+                    for (int32_t w = tid; w < itemWords; w += kAtlasBitThreads)                 /* mask_write, lightmap.c:209-230 */
                     {
-                        const unsigned long long iw = itemInLds ? sItem[w] : g.itemBits[w];
+                        const unsigned long long iw = itemInLds ? item[w] : itemHbm[w];
                         if (!iw) continue;
-                        const int32_t by = w / itemRowWords, pos = tx + 64 * (w % itemRowWords), wi = pos >> 6, sh = pos & 63;
+                        const int32_t by = itemRowWords == 1 ? w : w / itemRowWords;
+                        const int32_t pos = tx + 64 * (w - by * itemRowWords), wi = pos >> 6, sh = pos & 63;
                         unsigned long long* arow = sAtlas + (ty + by) * rowWords;
                         atomicOr(&arow[wi], iw << sh);
                         if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], iw >> (64 - sh));
                     }
-                    __syncthreads();
-                    if (tid == 0) { a.translations[2 * c] = tx; a.translations[2 * c + 1] = ty; a.atlasIndex[c] = at; a.atlasCharts[at] += 1; }
+                    dirty = true;
+                    if (tid == 0) { a.translations[2 * i] = tx; a.translations[2 * i + 1] = ty; a.atlasIndex[i] = at; atomicAdd(&a.atlasCharts[at], 1); }
                     prevAtlas = at; prevRow = ty;
                     placed = true;
                 }
@@ -585,10 +756,24 @@ __global__ __launch_bounds__(kAtlasThreads) void k_atlas_place_bits(AtlasBitArgs
                 ++atlasCount;
             }
         }
-        if (!placed) { if (tid == 0) { a.status[0] = c; a.status[1] = atlasCount; } return; }
-        __syncthreads();                                         /* sItem is rebuilt for the next chart */
+        if (!placed) { if (tid == 0) { a.status[0] = i; a.status[1] = atlasCount; } return; }
+        /* the next chart's rows into the item buffer: a small one beside a small one needs no barrier of its own */
+        if (i + 1 < n)
+        {
+            if (small && nextSmall) { half ^= 1; if (tid < nextWords) sItem[half * kItemWordsSmall + tid] = pre; }
+            else
+            {
+                __syncthreads();                                     /* the rows in use have been read */
+                if (nextSmall) { half = 0; if (tid < nextWords) sItem[tid] = pre; }
+                else if (nextWords <= kItemWordsLds) for (int32_t w = tid; w < nextWords; w += kAtlasBitThreads) sItem[w] = g.bits[(size_t)nxt.wordOff + w];
+            }
+        }
+        __syncthreads();                                             /* the atlas with this chart in it, and the next chart's rows */
+        cur = nxt;
+        nxt.bw = __builtin_amdgcn_readfirstlane(aheadV.x); nxt.bh = __builtin_amdgcn_readfirstlane(aheadV.y);
+        nxt.area = __int_as_float(__builtin_amdgcn_readfirstlane(aheadV.z)); nxt.wordOff = (uint32_t)__builtin_amdgcn_readfirstlane(aheadV.w);
     }
-    if (tid == 0) a.status[1] = atlasCount;
+    if (tid == 0) { a.status[1] = atlasCount; a.status[2] = (int32_t)round; a.status[3] = swaps; }
 }
 
 struct DevBuf
@@ -953,7 +1138,22 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     }
     const bool asBits = atlasSize <= kAtlasBitsMaxSize && !getenv("PIMGPU_ATLAS_BYTES");      /* the byte form: larger atlases, and A/B runs of the tests */
     const size_t rowWords = ((size_t)atlasSize + 63) / 64, atlasWords = (size_t)atlasSize * rowWords;
-    DevBuf maskBuf, offBuf, sizeBuf, areaBuf, orderBuf, atlasBuf, outBuf, itemBuf;
+    /* the bit form takes the charts in placement order: descriptors and the offsets of their bit rows */
+    std::vector<ChartDesc> desc;
+    uint64_t bitWords = 0;
+    if (asBits)
+    {
+        desc.resize((size_t)chartCount);
+        for (int32_t i = 0; i < chartCount; ++i)
+        {
+            const int32_t c = order[i];
+            ChartDesc& d = desc[(size_t)i];
+            d.bw = maskSizes[2 * c]; d.bh = maskSizes[2 * c + 1]; d.area = areas[c]; d.wordOff = (uint32_t)bitWords;
+            bitWords += (uint64_t)d.bh * (uint64_t)((d.bw + 63) >> 6);
+            if (bitWords >= (1ull << 32)) { set_error("lightmap_atlas_place: the charts' masks exceed 2^32 words of 64 texels"); return PIMGPU_E_LIMIT; }
+        }
+    }
+    DevBuf maskBuf, offBuf, sizeBuf, areaBuf, orderBuf, atlasBuf, outBuf, descBuf, bitBuf;
     if ((rc = maskBuf.alloc((size_t)total))) return rc;
     if ((rc = offBuf.alloc(8 * (size_t)chartCount))) return rc;
     if ((rc = sizeBuf.alloc(8 * (size_t)chartCount))) return rc;
@@ -961,7 +1161,7 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     if ((rc = orderBuf.alloc(4 * (size_t)chartCount))) return rc;
     const size_t atlasBytes = asBits ? 8 * atlasWords * (size_t)atlasCap : aBytes * (size_t)atlasCap;
     if ((rc = atlasBuf.alloc(atlasBytes))) return rc;
-    if (asBits && (rc = itemBuf.alloc(8 * atlasWords))) return rc;
+    if (asBits && ((rc = descBuf.alloc(sizeof(ChartDesc) * (size_t)chartCount)) || (rc = bitBuf.alloc(8 * (size_t)bitWords)))) return rc;
     const size_t outInts = 3 * (size_t)chartCount + (size_t)atlasCap + 4;
     if ((rc = outBuf.alloc(4 * outInts))) return rc;
     PT_HIP(hipMemcpyAsync(maskBuf.p, masks, (size_t)total, hipMemcpyHostToDevice, st));
@@ -969,6 +1169,7 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     PT_HIP(hipMemcpyAsync(sizeBuf.p, maskSizes, 8 * (size_t)chartCount, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(areaBuf.p, areas, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(orderBuf.p, order, 4 * (size_t)chartCount, hipMemcpyHostToDevice, st));
+    if (asBits) PT_HIP(hipMemcpyAsync(descBuf.p, desc.data(), sizeof(ChartDesc) * (size_t)chartCount, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(atlasBuf.p, 0, atlasBytes, st));
     PT_HIP(hipMemsetAsync(outBuf.p, 0xff, 4 * outInts, st));            /* -1: not placed / no failure */
     AtlasArgs a;
@@ -980,15 +1181,18 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
     PT_HIP(hipMemsetAsync(a.atlasCharts, 0, 4 * (size_t)atlasCap, st));
     if (asBits)
     {
-        AtlasBitArgs g; g.a = a; g.atlasBits = (unsigned long long*)atlasBuf.p; g.itemBits = (unsigned long long*)itemBuf.p;
-        k_atlas_place_bits<<<1, kAtlasThreads, 0, st>>>(g);
+        AtlasBitArgs g; g.a = a; g.atlasBits = (unsigned long long*)atlasBuf.p; g.desc = (const ChartDesc*)descBuf.p; g.bits = (const unsigned long long*)bitBuf.p;
+        k_chart_bits<<<(uint32_t)(((size_t)chartCount * 64 + 255) / 256), 256, 0, st>>>(a.masks, a.maskOffsets, a.order, g.desc, chartCount, (unsigned long long*)bitBuf.p);
+        k_atlas_place_bits<<<1, kAtlasBitThreads, 0, st>>>(g);
     }
     else k_atlas_place<<<1, kAtlasThreads, 0, st>>>(a);
     PT_HIP(hipGetLastError());
     std::vector<int32_t> host(outInts);
     PT_HIP(hipMemcpyAsync(host.data(), out, 4 * outInts, hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
-    const int32_t failedChart = host[3 * (size_t)chartCount + (size_t)atlasCap];
+    if (asBits && getenv("PIMGPU_ATLAS_LOG")) fprintf(stderr, "atlas_place: %d charts, %d rounds of the scan, %d atlas swaps\n", chartCount, host[3 * (size_t)chartCount + (size_t)atlasCap + 2], host[3 * (size_t)chartCount + (size_t)atlasCap + 3]);
+    int32_t failedChart = host[3 * (size_t)chartCount + (size_t)atlasCap];
+    if (asBits && failedChart >= 0) failedChart = order[failedChart];          /* the bit form speaks in placement order */
     if (failedChart >= 0)
     {
         set_error("lightmap_atlas_place: chart %d (mask %d x %d) fits in none of the %d atlases of %d^2, %d more allowed (the reference's AtlasFn does not return here, lightmap.c:808-818)",
@@ -996,8 +1200,20 @@ int pimgpu_lightmap_atlas_place(const uint8_t* masks, const int64_t* maskOffsets
             atlasCap - host[3 * (size_t)chartCount + (size_t)atlasCap + 1]);
         return PIMGPU_E_LIMIT;
     }
-    memcpy(translations, host.data(), 8 * (size_t)chartCount);
-    memcpy(atlasIndex, host.data() + 2 * (size_t)chartCount, 4 * (size_t)chartCount);
+    if (asBits)
+    {
+        for (int32_t i = 0; i < chartCount; ++i)
+        {
+            const int32_t c = order[i];
+            translations[2 * c] = host[2 * (size_t)i]; translations[2 * c + 1] = host[2 * (size_t)i + 1];
+            atlasIndex[c] = host[2 * (size_t)chartCount + (size_t)i];
+        }
+    }
+    else
+    {
+        memcpy(translations, host.data(), 8 * (size_t)chartCount);
+        memcpy(atlasIndex, host.data() + 2 * (size_t)chartCount, 4 * (size_t)chartCount);
+    }
     int32_t used = 0;
     for (int32_t i = 0; i < atlasCap; ++i) if (host[3 * (size_t)chartCount + (size_t)i] > 0) ++used;        /* atlases_create, lightmap.c:862-870 */
     if (usedAtlases) *usedAtlases = used;

@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define kTagChart 0x43485254u               /* 'CHRT' */
 enum { kChartSplits = 2, kSplitAttempts = 16, kSplitRounds = 1000 };
@@ -438,9 +439,19 @@ static LmPack pack_fail(const char* what, const char* detail)
     return none;
 }
 
+/* PIM_LMPACK_LOG=1: seconds per step of LmPack_Pack on stderr */
+static double pack_now(void) { struct timespec ts; timespec_get(&ts, TIME_UTC); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void pack_step(const char* what, double* t0)
+{
+    const double t1 = pack_now();
+    if (getenv("PIM_LMPACK_LOG")) fprintf(stderr, "[lm] %-24s %.3f s\n", what, t1 - *t0);
+    *t0 = t1;
+}
+
 LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsPerUnit, float distThresh, float degThresh, uint32_t seed)
 {
     ms_packError[0] = 0;
+    double stepT = pack_now();
     if (!drawables || atlasSize <= 0 || !(texelsPerUnit > 0.0f)) return pack_fail("LmPack_Pack: bad argument", NULL);
     const float maxWidth = atlasSize / 3.0f;                            /* lm.c:1065 */
 
@@ -450,9 +461,11 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
     if (!nodes) return pack_fail("LmPack_Pack: out of memory", NULL);
     if (nodeCount > 0 && pimgpu_lightmap_chartnodes(drawables, texelsPerUnit, nodes, nodeCount, &nodeCount)) { free(nodes); return pack_fail("chartnodes_create", pimgpu_last_error()); }
 
+    pack_step("chartnodes_create", &stepT);
     i32* chartFirst = NULL; i32 chartCount = 0;
     if (!group_charts(&nodes, nodeCount, distThresh, degThresh, maxWidth, seed, &chartFirst, &chartCount)) { free(nodes); return pack_fail("chart_group: out of memory", NULL); }
 
+    pack_step("chart_group", &stepT);
     LmPack pack; memset(&pack, 0, sizeof(pack));
     float* areas = malloc(sizeof(float) * (size_t)(chartCount + 1));
     i32* maskSizes = malloc(sizeof(i32) * 2 * (size_t)(chartCount + 1));
@@ -471,6 +484,7 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
         if (!failed) for (i32 c = 0; c < chartCount; ++c) { maskOffsets[c] = total; total += (int64_t)maskSizes[2 * c] * maskSizes[2 * c + 1]; }
         if (!failed && !(masks = malloc((size_t)(total > 0 ? total : 1)))) failed = "LmPack_Pack: out of memory";
         if (!failed && pimgpu_lightmap_chart_masks(nodes, chartFirst, chartCount, maskSizes, maskOffsets, masks)) failed = "ChartMaskFn";
+        pack_step("chart masks", &stepT);
         if (!failed)
         {
             LmPack_SortCharts(areas, chartCount, order);                /* chart_sort, lm.c:1074 */
@@ -479,6 +493,7 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
              * then search for ever, further atlases are opened, up to four times the estimate and sixteen more */
             if (pimgpu_lightmap_atlas_place(masks, maskOffsets, maskSizes, areas, order, chartCount, atlasSize, atlasCount, atlasCount * 4 + 16, translations, atlasIndex, &used))
                 failed = "atlases_create";
+            pack_step("sort + atlases_create", &stepT);
         }
     }
     if (!failed)
@@ -495,14 +510,17 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
             Lightmap_New(&pack.lightmaps[i], atlasSize);
             if (!pack.lightmaps[i].probes[0]) failed = "Lightmap_New";
         }
+        pack_step("Lightmap_New pages", &stepT);
         if (!failed && used > 0)
         {
             assign_charts(drawables, nodes, chartFirst, chartCount, translations, atlasIndex, pack.lightmaps);
+            pack_step("chartnodes_assign", &stepT);
             i32* texIds = malloc(sizeof(i32) * (size_t)used);
             if (texIds)
             {
                 for (i32 i = 0; i < used; ++i) texIds[i] = (i32)pack.lightmaps[i].slot.index;
                 LmPack_EmbedAttributes(drawables, pack.lightmaps, texIds, used);      /* lm.c:1092 */
+                pack_step("EmbedAttributes", &stepT);
                 free(texIds);
             }
             else failed = "LmPack_Pack: out of memory";

@@ -46,5 +46,7 @@ timed("chart_sort_host", lambda: host.LmPack_SortCharts(areas.ctypes.data, nc, o
 est = int(np.ceil(np.ceil(areas).astype(np.int64).sum() / (S * S))) or 1
 out["atlas_estimate"] = est
 tr, idx, used = timed("atlas_place_gpu", lambda: api.lightmap_atlas_place(masks, offsets, sizes, areas, order, S, est, est * 4 + 16))
+import zlib
+out["placement_crc32"] = zlib.crc32(np.ascontiguousarray(tr).tobytes() + np.ascontiguousarray(idx).tobytes())
 out["atlases_used"] = int(used); out["charts_per_s_placed"] = round(nc / out["atlas_place_gpu_s"], 1)
 print(json.dumps(out))

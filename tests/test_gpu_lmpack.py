@@ -87,6 +87,25 @@ def test_atlas_place_matches_one_worker(n, lo, hi, S, seed, form, monkeypatch):
         view |= m
 
 
+@pytest.mark.parametrize("n,lo,hi,S,seed,fill", [(600, 60, 68, 512, 7, 0.8), (400, 62, 66, 512, 10, 1.0), (800, 14, 18, 256, 8, 0.9), (500, 30, 34, 320, 9, 1.0),
+                                                 (3000, 5, 20, 1024, 11, 1.0), (1500, 3, 64, 1000, 12, 0.7)])
+def test_atlas_place_on_the_word_forms_thresholds(n, lo, hi, S, seed, fill):
+    """the bit form tests 64 candidate columns per word for masks of up to 64 x 64 texels, with 16, 32 or 64 lanes per candidate
+    row: masks around 16 / 32 / 64 rows and 64 columns (a run of set bits that ends at bit 63; one column more takes the form for
+    wide masks), solid masks (one run per row) and ragged ones (several), an atlas row of 15.6 words, thousands of charts in one
+    atlas (rounds of several candidate rows, resets of the hints as the areas fall)"""
+    gpu_init()
+    masks, offsets, sizes, areas = random_masks(n, lo, hi, seed, fill=fill)
+    order = oracle_sort(areas)
+    lib = load_oracle(True)
+    lib.orc_lightmap_atlas_estimate.restype = C.c_int32
+    count = lib.orc_lightmap_atlas_estimate(p(areas), C.c_int32(n), C.c_int32(S))
+    want = oracle_place(masks, offsets, sizes, areas, order, S, count, count * 4 + 16)
+    got = api.lightmap_atlas_place(masks, offsets, sizes, areas, order, S, count, count * 4 + 16)
+    assert got[2] == want[2]
+    assert (got[1] == want[1]).all() and (got[0] == want[0]).all()
+
+
 def test_atlas_place_reports_what_the_reference_spins_on():
     gpu_init()
     masks, offsets, sizes, areas = random_masks(12, 6, 12, 5)
