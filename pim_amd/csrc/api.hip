@@ -336,11 +336,17 @@ void* pimgpu_host_alloc(size_t bytes)
     {
         std::vector<std::thread> pool;
         const size_t per = ((bytes + workers - 1) / workers + 4095) & ~(size_t)4095;
-        for (unsigned k = 0; k < workers; ++k)
+        size_t done = 0;                                   /* bytes handed to a thread so far */
+        try
         {
-            const size_t lo = std::min(bytes, per * k), hi = std::min(bytes, per * (k + 1));
-            if (hi > lo) pool.emplace_back([=] { memset((char*)p + lo, 0, hi - lo); });
+            for (unsigned k = 0; k + 1 < workers; ++k)
+            {
+                const size_t lo = std::min(bytes, per * k), hi = std::min(bytes, per * (k + 1));
+                if (hi > lo) { pool.emplace_back([=] { memset((char*)p + lo, 0, hi - lo); }); done = hi; }
+            }
         }
+        catch (...) { }                                    /* no more threads to be had: this one clears the rest */
+        memset((char*)p + done, 0, bytes - done);
         for (auto& t : pool) t.join();
     }
     return p;

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from pim_amd import api, scenes
-from tests.gpu_util import assert_bits_equal
+from tests.gpu_util import assert_bits_equal, gpu_init
 from tests.util import OracleScene
 
 pytestmark = pytest.mark.gpu
@@ -323,3 +323,17 @@ def test_lightmap_checkpoint_resumes_bit_exact(tmp_path):
     host.LmPack_Del(pack)
     host.PtScene_Del(scene)
     host.PtSys_SetLightmapUploader(None, None)
+
+
+def test_page_locked_blocks_come_zeroed():
+    """pimgpu_host_alloc stands for Tex_Calloc (lightmap.c:90-110): blocks above 32 MB are cleared by several threads, in parts
+    rounded to pages; sizes on and off those boundaries, dirtied and freed in between so that a reused block shows"""
+    gpu_init()
+    for count in (1, 4095, (32 << 20) // 4 - 1, (48 << 20) // 4 + 3, 27 * 1024 * 1024 + 5):
+        a = api.host_array(count, np.float32)
+        assert a.shape == (count,) and not a.any()
+        a[:] = 1.0
+        del a
+        b = api.host_array(count, np.uint32)
+        assert not b.any()
+        del b
