@@ -565,6 +565,10 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
         unsigned long long pre = 0ull;
         if (nextSmall && tid < nextWords) pre = g.bits[(size_t)nxt.wordOff + tid];
         if (area < (prevArea * 0.9f)) { prevArea = area; prevAtlas = 0; prevRow = PT_ROW_RESET; }
+        /* the word form below (masks of up to 64 x 64): lane `by` of a group of G keeps row `by` of the mask, for the test and for the write */
+        const bool wordForm = itemRowWords == 1 && bh <= 64;
+        const int32_t gShift = bh <= 16 ? 4 : (bh <= 32 ? 5 : 6), G = 1 << gShift;         /* (shifts: G is not a constant, and a division is forty instructions) */
+        const unsigned long long rowOfLane = (wordForm && (tid & (G - 1)) < bh) ? item[tid & (G - 1)] : 0ull;
         bool placed = false;
         for (int attempt = 0; attempt < 3 && !placed; ++attempt)
         {
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                         resident = at; dirty = false; ++swaps;
                         __syncthreads();
                     }
-                    if (itemRowWords == 1 && bh <= 64)
+                    if (wordForm)
                     {
                         /* A mask of at most 64 x 64 texels (nearly every chart): the test runs over WORDS of candidates.  Wave w
                          * owns the columns 64 w .. 64 w + 63 of a candidate row y; its lane `by` takes row `by` of the mask and
@@ -593,13 +597,13 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                          * (atlas row y + by) >> b -- run by run, a run of L bits in log2 L shift-ORs.  The OR over the lanes is
                          * the blocked columns of row y; the first clear bit is the first fit.  Masks of up to 16 (32) rows share
                          * a wave four (two) candidate rows at a time. */
-                        const int32_t G = bh <= 16 ? 16 : (bh <= 32 ? 32 : 64), perWave = 64 / G;
+                        const int32_t perWave = 64 >> gShift;
                         const int32_t lane = tid & 63, wave = tid >> 6;
-                        const int32_t gi = lane / G, by = lane & (G - 1);
+                        const int32_t gi = lane >> gShift, by = lane & (G - 1);
                         /* a unit of work = (candidate row j, word w of columns), numbered u = 16 j + w in candidate order; a group of
                          * G lanes takes one unit, groups in unit order over the waves: a round of ONE candidate row (nine in ten) keeps
                          * 16 / perWave waves busy, one per SIMD when masks have <= 16 rows, and the others step aside */
-                        const unsigned long long iw = by < bh ? item[by] : 0ull;
+                        const unsigned long long iw = rowOfLane;
                         int32_t rows = 1;                                            /* candidate rows in the next round */
                         for (int32_t yBase = y0; yBase < rangeY && foundY < 0; )
                         {
@@ -733,10 +737,11 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                     const int32_t ty = foundY, tx = foundX;
                     for (int32_t w = tid; w < itemWords; w += kAtlasBitThreads)                 /* mask_write, lightmap.c:209-230 */
                     {
-                        const unsigned long long iw = itemInLds ? item[w] : itemHbm[w];
+                        const unsigned long long iw = wordForm ? rowOfLane : (itemInLds ? item[w] : itemHbm[w]);     /* word form: w = tid < bh <= G */
                         if (!iw) continue;
-                        const int32_t by = itemRowWords == 1 ? w : w / itemRowWords;
-                        const int32_t pos = tx + 64 * (w - by * itemRowWords), wi = pos >> 6, sh = pos & 63;
+                        int32_t by = w, pos = tx;
+                        if (itemRowWords != 1) { by = w / itemRowWords; pos = tx + 64 * (w - by * itemRowWords); }
+                        const int32_t wi = pos >> 6, sh = pos & 63;
                         unsigned long long* arow = sAtlas + (ty + by) * rowWords;
                         atomicOr(&arow[wi], iw << sh);
                         if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], iw >> (64 - sh));
