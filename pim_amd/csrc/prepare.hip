@@ -517,6 +517,29 @@ __device__ __forceinline__ uint32_t row16_or(uint32_t v)
     return v;
 }
 
+/* the columns x of a word of 64 candidates at which row `iw` of a mask collides with the atlas row whose words at and after the
+ * candidates' word are A0, A1: the OR over the set bits b of iw of (A1:A0) >> b, a run of L set bits in log2 L shift-ORs */
+__device__ __forceinline__ unsigned long long blocked_columns(unsigned long long A0, unsigned long long A1, unsigned long long iw)
+{
+    unsigned long long B = 0ull, m = iw;
+    while (m)
+    {
+        const int32_t l = __builtin_ctzll(m);
+        const unsigned long long run = ~(m >> l);
+        const int32_t L = run ? __builtin_ctzll(run) : 64;               /* l + L <= 64 */
+        m = (l + L >= 64) ? 0ull : (m & (~0ull << (l + L)));
+        unsigned long long U0 = (A0 >> l) | (l ? (A1 << (64 - l)) : 0ull), U1 = A1 >> l;
+        for (int32_t k = 1; k < L; )
+        {
+            const int32_t sft = min(k, L - k);
+            U0 |= (U0 >> sft) | (U1 << (64 - sft)); U1 |= U1 >> sft;
+            k += sft;
+        }
+        B |= U0;
+    }
+    return B;
+}
+
 __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitArgs g)
 {
     const AtlasArgs& a = g.a;
@@ -533,7 +556,8 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
     int32_t atlasCount = a.atlasCount;
     int32_t resident = -1;                                      /* the atlas whose bits are in LDS */
     bool dirty = false;                                         /* ... and whether it differs from its copy in HBM */
-    uint32_t round = 0;                                         /* rounds of the scan so far: the result slot in use is round % 3 */
+    uint32_t round = 0;                                         /* rounds of the scan so far */
+    uint32_t slot = 0;                                          /* the result slot in use, round % 3 (kept, not divided out) */
     int32_t swaps = 0;
     if (tid < 3) sBest[tid] = 0x7fffffff;
     int32_t opaqueZero;                                         /* 0, in a vector register the compiler knows nothing about */
@@ -570,6 +594,44 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
         const int32_t gShift = bh <= 16 ? 4 : (bh <= 32 ? 5 : 6), G = 1 << gShift;         /* (shifts: G is not a constant, and a division is forty instructions) */
         const unsigned long long rowOfLane = (wordForm && (tid & (G - 1)) < bh) ? item[tid & (G - 1)] : 0ull;
         bool placed = false;
+        /* The common chart by the short road: no more than 16 rows, the search goes on in the atlas that is in LDS from the row of the
+         * chart before, and that row has room -- ONE round of one candidate row, 16 groups of 16 lanes for its 16 words of columns.
+         * A wave issues an instruction every fourth cycle at best, so what a chart costs is the instructions on its road; this one has
+         * no loops over attempts, atlases, rows and units around it.  Finding nothing, it has changed nothing (a round was spent), and
+         * the general search below starts from the same hints. */
+        if (wordForm && gShift == 4 && resident == prevAtlas && prevRow != PT_ROW_RESET && S - bw > 0 && S - bh > prevRow)
+        {
+            if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
+            const int32_t w = tid >> 4, by = tid & 15;
+            const int32_t nvalid = (S - bw) - 64 * w;
+            unsigned long long B = 0ull;
+            if (w < rowWords && rowOfLane)
+            {
+                const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
+                B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+            }
+            const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
+            const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
+            const unsigned long long open = ~(((unsigned long long)hi << 32) | lo) & validMask;
+            const unsigned long long vote = __ballot(by == 0 && open != 0ull);
+            if (vote && (tid & 63) == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
+            __syncthreads();
+            const int32_t best = sBest[slot];
+            ++round; slot = slot == 2u ? 0u : slot + 1u;
+            if (best != 0x7fffffff)
+            {
+                if (tid < bh && rowOfLane)                                               /* mask_write, lightmap.c:209-230 */
+                {
+                    const int32_t wi = best >> 6, sh = best & 63;
+                    unsigned long long* arow = sAtlas + (prevRow + tid) * rowWords;
+                    atomicOr(&arow[wi], rowOfLane << sh);
+                    if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], rowOfLane >> (64 - sh));
+                }
+                dirty = true;
+                if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = prevRow; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
+                placed = true;
+            }
+        }
         for (int attempt = 0; attempt < 3 && !placed; ++attempt)
         {
             for (int32_t at = prevAtlas; at < atlasCount && !placed; ++at)
@@ -607,8 +669,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                         int32_t rows = 1;                                            /* candidate rows in the next round */
                         for (int32_t yBase = y0; yBase < rangeY && foundY < 0; )
                         {
-                            const uint32_t slot = round % 3u;
-                            if (tid == 0) sBest[(round + 1u) % 3u] = 0x7fffffff;
+                            if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
                             const int32_t units = rows * 16;
                             for (int32_t u0 = wave * perWave; u0 < units; u0 += (kAtlasBitThreads / 64) * perWave)
                             {
@@ -621,22 +682,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                                 {
                                     const unsigned long long* arow = sAtlas + (y + by) * rowWords;
                                     const unsigned long long A0 = arow[w], A1 = (w + 1 < rowWords) ? arow[w + 1] : 0ull;
-                                    unsigned long long m = iw;
-                                    while (m)
-                                    {
-                                        const int32_t l = __builtin_ctzll(m);
-                                        const unsigned long long run = ~(m >> l);
-                                        const int32_t L = run ? __builtin_ctzll(run) : 64;               /* l + L <= 64 */
-                                        m = (l + L >= 64) ? 0ull : (m & (~0ull << (l + L)));
-                                        unsigned long long U0 = (A0 >> l) | (l ? (A1 << (64 - l)) : 0ull), U1 = A1 >> l;
-                                        for (int32_t k = 1; k < L; )
-                                        {
-                                            const int32_t sft = min(k, L - k);
-                                            U0 |= (U0 >> sft) | (U1 << (64 - sft)); U1 |= U1 >> sft;
-                                            k += sft;
-                                        }
-                                        B |= U0;
-                                    }
+                                    B = blocked_columns(A0, A1, iw);
                                 }
                                 {
                                     uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
@@ -656,7 +702,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                             }
                             __syncthreads();
                             const int32_t best = sBest[slot];
-                            ++round;
+                            ++round; slot = slot == 2u ? 0u : slot + 1u;
                             if (best != 0x7fffffff) { foundY = yBase + (best >> 10); foundX = best & 1023; }
                             else { yBase += rows; rows = min(64, rows * 2); }
                         }
@@ -671,8 +717,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                     int32_t rows = 1;                                                /* passes per lane in the next round */
                     for (int32_t yBase = y0; yBase < rangeY && foundY < 0; )
                     {
-                        const uint32_t slot = round % 3u;
-                        if (tid == 0) sBest[(round + 1u) % 3u] = 0x7fffffff;
+                        if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
                         bool voted = false;
                         for (int32_t j = 0; j < rows && !voted; ++j)
                         for (int32_t xb = 0; xb < rangeX && !voted; xb += kAtlasBitThreads)
@@ -726,7 +771,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
                         }
                         __syncthreads();
                         const int32_t best = sBest[slot];
-                        ++round;
+                        ++round; slot = slot == 2u ? 0u : slot + 1u;
                         if (best != 0x7fffffff) { foundY = yBase + (best >> 10); foundX = best & 1023; }
                         else { yBase += rows * rowsPer; rows = min(kAtlasRowsMax, rows * 2); }
                     }
