@@ -571,6 +571,57 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
     __syncthreads();
     for (int32_t i = 0; i < n; ++i)
     {
+        /* The common charts by the short road, as many in a row as come: no more than 16 rows and 64 columns, the search goes on in
+         * the atlas that is in LDS from the row of the chart before, that row has room, and the chart behind it is small as well --
+         * ONE round of one candidate row, 16 groups of 16 lanes for its 16 words of columns.  A wave issues an instruction every
+         * fourth cycle at best, so what a chart costs is the instructions on its road: this loop has nothing of the general search
+         * around it (attempts, atlases, rows, units, swaps) and its state stays out of the way in between.  A chart it cannot take,
+         * or for which the round finds nothing, is left untouched for the general search below (a round was spent). */
+        for (;;)
+        {
+            const int32_t bw = cur.bw, bh = cur.bh;
+            const int32_t nextWords = nxt.bh * ((nxt.bw + 63) >> 6);
+            if (!(bw <= 64 && bh <= 16 && i + 1 < n && nextWords <= kItemWordsSmall && !(cur.area < (prevArea * 0.9f)) && resident == prevAtlas
+                  && prevRow != PT_ROW_RESET && S - bw > 0 && S - bh > prevRow)) break;
+            const int4 aheadV = ((const int4*)g.desc)[min(i + 2, n - 1) + opaqueZero];
+            unsigned long long pre = 0ull;
+            if (tid < nextWords) pre = g.bits[(size_t)nxt.wordOff + tid];
+            const int32_t w = tid >> 4, by = tid & 15;
+            const unsigned long long rowOfLane = by < bh ? sItem[half * kItemWordsSmall + by] : 0ull;
+            if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
+            const int32_t nvalid = (S - bw) - 64 * w;
+            unsigned long long B = 0ull;
+            if (w < rowWords && rowOfLane)
+            {
+                const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
+                B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+            }
+            const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
+            const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
+            const unsigned long long open = ~(((unsigned long long)hi << 32) | lo) & validMask;
+            const unsigned long long vote = __ballot(by == 0 && open != 0ull);
+            if (vote && (tid & 63) == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
+            __syncthreads();
+            const int32_t best = sBest[slot];
+            ++round; slot = slot == 2u ? 0u : slot + 1u;
+            if (best == 0x7fffffff) break;
+            if (tid < bh && rowOfLane)                                               /* mask_write, lightmap.c:209-230 (tid = by of group 0) */
+            {
+                const int32_t wi = best >> 6, sh = best & 63;
+                unsigned long long* arow = sAtlas + (prevRow + tid) * rowWords;
+                atomicOr(&arow[wi], rowOfLane << sh);
+                if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], rowOfLane >> (64 - sh));
+            }
+            dirty = true;
+            if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = prevRow; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
+            half ^= 1;
+            if (tid < nextWords) sItem[half * kItemWordsSmall + tid] = pre;
+            __syncthreads();                                             /* the atlas with this chart in it, and the next chart's rows */
+            cur = nxt;
+            nxt.bw = __builtin_amdgcn_readfirstlane(aheadV.x); nxt.bh = __builtin_amdgcn_readfirstlane(aheadV.y);
+            nxt.area = __int_as_float(__builtin_amdgcn_readfirstlane(aheadV.z)); nxt.wordOff = (uint32_t)__builtin_amdgcn_readfirstlane(aheadV.w);
+            ++i;
+        }
         /* the descriptor two charts ahead, as a VECTOR load whose result is made uniform only at the end of this chart's
          * placement: a uniform load is waited for where it is issued (its readfirstlane follows at once), and that wait is a
          * trip to L2 or HBM on the chain from chart to chart */
@@ -594,44 +645,6 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
         const int32_t gShift = bh <= 16 ? 4 : (bh <= 32 ? 5 : 6), G = 1 << gShift;         /* (shifts: G is not a constant, and a division is forty instructions) */
         const unsigned long long rowOfLane = (wordForm && (tid & (G - 1)) < bh) ? item[tid & (G - 1)] : 0ull;
         bool placed = false;
-        /* The common chart by the short road: no more than 16 rows, the search goes on in the atlas that is in LDS from the row of the
-         * chart before, and that row has room -- ONE round of one candidate row, 16 groups of 16 lanes for its 16 words of columns.
-         * A wave issues an instruction every fourth cycle at best, so what a chart costs is the instructions on its road; this one has
-         * no loops over attempts, atlases, rows and units around it.  Finding nothing, it has changed nothing (a round was spent), and
-         * the general search below starts from the same hints. */
-        if (wordForm && gShift == 4 && resident == prevAtlas && prevRow != PT_ROW_RESET && S - bw > 0 && S - bh > prevRow)
-        {
-            if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
-            const int32_t w = tid >> 4, by = tid & 15;
-            const int32_t nvalid = (S - bw) - 64 * w;
-            unsigned long long B = 0ull;
-            if (w < rowWords && rowOfLane)
-            {
-                const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
-                B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
-            }
-            const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
-            const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
-            const unsigned long long open = ~(((unsigned long long)hi << 32) | lo) & validMask;
-            const unsigned long long vote = __ballot(by == 0 && open != 0ull);
-            if (vote && (tid & 63) == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
-            __syncthreads();
-            const int32_t best = sBest[slot];
-            ++round; slot = slot == 2u ? 0u : slot + 1u;
-            if (best != 0x7fffffff)
-            {
-                if (tid < bh && rowOfLane)                                               /* mask_write, lightmap.c:209-230 */
-                {
-                    const int32_t wi = best >> 6, sh = best & 63;
-                    unsigned long long* arow = sAtlas + (prevRow + tid) * rowWords;
-                    atomicOr(&arow[wi], rowOfLane << sh);
-                    if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], rowOfLane >> (64 - sh));
-                }
-                dirty = true;
-                if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = prevRow; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
-                placed = true;
-            }
-        }
         for (int attempt = 0; attempt < 3 && !placed; ++attempt)
         {
             for (int32_t at = prevAtlas; at < atlasCount && !placed; ++at)
