@@ -374,7 +374,9 @@ int pimgpu_trace_download(const PimTrace* trace, float* color, float* albedo, fl
 /* Pt_Trace as the reference's callers use it (path_tracer.h:94, render_system.c:306-352: the host images are read right
  * after the call): pimgpu_trace_image and pimgpu_trace_download in one call (any image pointer may be NULL).  The pixels are
  * traced in shares, one after the other, and a share's part of the images travels to the host while the next share is
- * traced; the result is the same bit for bit.  Page-locked images (pimgpu_host_alloc) copy at the link's rate. */
+ * traced; the result is the same bit for bit.  Page-locked images (pimgpu_host_alloc) copy at the link's rate.  Two shares by
+ * default; the first one's size follows the tracing and copy times measured on this PimTrace's previous call (INTEGRATION.md,
+ * PIMGPU_HOST_FIRST). */
 int pimgpu_trace_image_host(PimScene* scene, PimTrace* trace, const PimCamera* camera, PimDofInfo* dof, const PimTraceParams* params,
     float* color, float* albedo, float* normal);
 /* device addresses of the float3 buffers (for torch.distributed reduce without a host copy) */
