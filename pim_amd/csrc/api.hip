@@ -329,8 +329,10 @@ void* pimgpu_host_alloc(size_t bytes)
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error("host_alloc: %zu bytes of page-locked memory", bytes); return nullptr; }
     /* zeroed like the Tex_Calloc it stands for; a lightmap page is 113 MB and a pack has dozens: several threads clear a large block
      * (the first touch of page-locked memory is cheap, the pages are there; one core's store rate is the limit) */
-    const size_t kPart = (size_t)16 << 20;
-    const unsigned workers = (unsigned)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), bytes / kPart);
+    const size_t kPart = (size_t)4 << 20;
+    const char* e = getenv("PIMGPU_HOST_CLEAR_THREADS");                     /* tuning knob */
+    const size_t clearThreads = (size_t)std::max(1, std::min(64, (e && *e) ? atoi(e) : 16));
+    const unsigned workers = (unsigned)std::min<size_t>(std::min<size_t>(clearThreads, std::max(1u, std::thread::hardware_concurrency())), bytes / kPart);
     if (workers <= 1) memset(p, 0, bytes);
     else
     {
