@@ -418,15 +418,19 @@ i32 AmbCube_Bake(PtScene* scene, AmbCube_t* pCube, float4 origin, i32 samples, i
 
 /* ---- lightmaps ---- */
 
-void Lightmap_New(Lightmap* lm, i32 size)
+void Lightmap_New(Lightmap* lm, i32 size) { Lightmap_NewIn(lm, size, NULL); }
+
+/* block: what Lightmap_New would allocate, made ahead by the caller (pimgpu_host_alloc of size * size * 27 floats, still zeroed:
+ * LmPack_Pack page-locks its pages on a second thread while the atlas search runs); NULL: allocated here.  The page owns it. */
+void Lightmap_NewIn(Lightmap* lm, i32 size, float* block)
 {
     memset(lm, 0, sizeof(*lm));
-    if (size <= 0) return;
+    if (size <= 0) { pimgpu_host_free(block); return; }
     lm->size = size;
     const size_t texelcount = (size_t)size * (size_t)size;
     /* [5] float4 | float3 | float3 | float, lightmap.c:90-110; Tex_Calloc there, page-locked here: LmPack_Bake copies a
      * page (113 MB at 1024^2) to the device and back on every call */
-    float* allocation = pimgpu_host_alloc(texelcount * 27 * sizeof(float));
+    float* allocation = block ? block : pimgpu_host_alloc(texelcount * 27 * sizeof(float));
     if (!allocation) { lm->size = 0; return; }
     for (i32 i = 0; i < kGiDirections; ++i) lm->probes[i] = (float4*)(allocation + texelcount * 4 * (size_t)i);
     lm->position = (float3*)(allocation + texelcount * 20);

@@ -92,6 +92,7 @@ typedef struct Lightmap_s
 typedef struct LmPack_s { float4 axii[kGiDirections]; Lightmap* lightmaps; i32 lmCount; i32 lmSize; float texelsPerMeter; } LmPack;
 void Lightmap_New(Lightmap* lm, i32 size);               /* lightmap.h:56, lightmap.c:81-133 (the Vulkan slot stays zero: the renderer's) */
 void Lightmap_Del(Lightmap* lm);                         /* :57 */
+void Lightmap_NewIn(Lightmap* lm, i32 size, float* block);   /* not in the reference: Lightmap_New over a page-locked, zeroed block made ahead (NULL: as Lightmap_New) */
 LmPack* LmPack_Get(void);                                /* :61: the pack LmPack_Bake works on (ms_pack, lightmap.c:79) */
 void LmPack_Del(LmPack* pack);                           /* :67 */
 void LmPack_Bake(PtScene* scene, float timeSlice, i32 spp);   /* :69, lightmap.c:1204-1223 */

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <threads.h>
 
 #define kTagChart 0x43485254u               /* 'CHRT' */
 enum { kChartSplits = 2, kSplitAttempts = 16, kSplitRounds = 1000 };
@@ -463,6 +464,18 @@ static LmPack pack_fail(const char* what, const char* detail)
     return none;
 }
 
+/* The pack's pages are page-locked blocks of 113 MB at 1024^2, and what such a block costs is the first touch of its pages (half a
+ * second for the 62 pages of a million triangles).  Their number is known, give or take one, before the atlas search starts
+ * (atlas_estimate), and the search keeps one GPU workgroup and no host core busy: a second thread makes the blocks meanwhile. */
+typedef struct { i32 count, size; float** blocks; } PagesAhead;
+static int pages_ahead_run(void* arg)
+{
+    PagesAhead* p = arg;
+    const size_t bytes = (size_t)p->size * (size_t)p->size * 27 * sizeof(float);
+    for (i32 i = 0; i < p->count; ++i) { p->blocks[i] = pimgpu_host_alloc(bytes); if (!p->blocks[i]) break; }
+    return 0;
+}
+
 /* PIM_LMPACK_LOG=1: seconds per step of LmPack_Pack on stderr */
 static double pack_now(void) { struct timespec ts; timespec_get(&ts, TIME_UTC); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static void pack_step(const char* what, double* t0)
@@ -501,6 +514,8 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
     const char* failed = NULL;
     if (!areas || !maskSizes || !maskOffsets || !order || !translations || !atlasIndex) failed = "LmPack_Pack: out of memory";
     i32 used = 0;
+    PagesAhead pre; memset(&pre, 0, sizeof(pre));
+    thrd_t preThread; bool preStarted = false;
     if (!failed && chartCount > 0)
     {
         if (pimgpu_lightmap_chart_layout(nodes, chartFirst, chartCount, areas, maskSizes)) failed = "ChartMaskFn";
@@ -515,8 +530,18 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
             const i32 atlasCount = atlas_estimate(atlasSize, areas, chartCount);
             /* atlas_estimate counts the charts' bounds without their 2-texel margins and does run short; where the reference would
              * then search for ever, further atlases are opened, up to four times the estimate and sixteen more */
+            const char* ahead = getenv("PIM_LMPACK_PAGES_AHEAD");                  /* "0": pages made after the search, on this thread */
+            const int64_t pageBytes = (int64_t)atlasSize * atlasSize * 27 * (int64_t)sizeof(float);
+            if (!(ahead && ahead[0] == '0') && (pre.blocks = calloc((size_t)atlasCount, sizeof(float*))))
+            {
+                pre.size = atlasSize;
+                pre.count = (i32)((int64_t)atlasCount * pageBytes <= (32ll << 30) ? atlasCount : (32ll << 30) / pageBytes);
+                preStarted = pre.count > 0 && thrd_create(&preThread, pages_ahead_run, &pre) == thrd_success;
+            }
             if (pimgpu_lightmap_atlas_place(masks, maskOffsets, maskSizes, areas, order, chartCount, atlasSize, atlasCount, atlasCount * 4 + 16, translations, atlasIndex, &used))
                 failed = "atlases_create";
+            if (preStarted) thrd_join(preThread, NULL);
+            else pre.count = 0;
             pack_step("sort + atlases_create", &stepT);
         }
     }
@@ -531,7 +556,9 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
         if (!pack.lightmaps) failed = "LmPack_Pack: out of memory";
         for (i32 i = 0; i < used && !failed; ++i)
         {
-            Lightmap_New(&pack.lightmaps[i], atlasSize);
+            float* block = (pre.blocks && i < pre.count) ? pre.blocks[i] : NULL;
+            if (block) pre.blocks[i] = NULL;                                    /* the page owns it now */
+            Lightmap_NewIn(&pack.lightmaps[i], atlasSize, block);
             if (!pack.lightmaps[i].probes[0]) failed = "Lightmap_New";
         }
         pack_step("Lightmap_New pages", &stepT);
@@ -552,6 +579,7 @@ LmPack LmPack_PackEx(const PimDrawables* drawables, i32 atlasSize, float texelsP
     }
     char detail[200]; detail[0] = 0;
     if (failed) snprintf(detail, sizeof(detail), "%s", pimgpu_last_error());
+    if (pre.blocks) { for (i32 i = 0; i < pre.count; ++i) pimgpu_host_free(pre.blocks[i]); free(pre.blocks); }      /* made ahead and not needed */
     free(nodes); free(chartFirst); free(areas); free(maskSizes); free(maskOffsets); free(order); free(translations); free(atlasIndex); free(masks);
     if (failed) { LmPack_Del(&pack); return pack_fail(failed, detail[0] ? detail : NULL); }
     return pack;

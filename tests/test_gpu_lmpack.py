@@ -173,10 +173,12 @@ def oracle_pack(dr, S, tpu, dist, deg, seed, tex_ids_of):
     return pages, used, nc
 
 
-@pytest.mark.parametrize("S,tpu", [(128, 4.0), (64, 2.0)])
-def test_lmpack_pack_end_to_end(S, tpu):
+@pytest.mark.parametrize("S,tpu,pages_ahead", [(128, 4.0, "1"), (64, 2.0, "1"), (64, 2.0, "0")])
+def test_lmpack_pack_end_to_end(S, tpu, pages_ahead, monkeypatch):
     """LmPack_Pack under its own name: the meshes' lightmap uvs and texture ids, the number of pages and every texel of
-    position | normal | sampleCounts equal the oracle's chain; then LmPack_Bake on those pages equals the oracle's bake"""
+    position | normal | sampleCounts equal the oracle's chain; then LmPack_Bake on those pages equals the oracle's bake.
+    (The pages are page-locked on a second thread while the atlas search runs, or after it on the caller's: both.)"""
+    monkeypatch.setenv("PIM_LMPACK_PAGES_AHEAD", pages_ahead)
     host = C.CDLL(os.path.join(ROOT, "pim_amd", "libpimhost.so"))
     host.PtSys_Ok.restype = C.c_bool
     seed, mb = 21, 3
