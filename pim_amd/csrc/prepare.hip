@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
     for (int32_t i = 0; i < n; ++i)
     {
         /* The common charts by the short road, as many in a row as come: no more than 16 rows and 64 columns, the search goes on in
-         * the atlas that is in LDS from the row of the chart before, that row has room, and the chart behind it is small as well --
+         * the atlas that is in LDS from the row of the chart before, that row has room, and the chart behind it has no more than 64 words of rows --
          * ONE round of one candidate row, 16 groups of 16 lanes for its 16 words of columns.  A wave issues an instruction every
          * fourth cycle at best, so what a chart costs is the instructions on its road: this loop has nothing of the general search
          * around it (attempts, atlases, rows, units, swaps) and its state stays out of the way in between.  A chart it cannot take,
@@ -581,11 +581,12 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
         {
             const int32_t bw = cur.bw, bh = cur.bh;
             const int32_t nextWords = nxt.bh * ((nxt.bw + 63) >> 6);
-            if (!(bw <= 64 && bh <= 16 && i + 1 < n && nextWords <= kItemWordsSmall && !(cur.area < (prevArea * 0.9f)) && resident == prevAtlas
+            if (!(bw <= 64 && bh <= 16 && i + 1 < n && nextWords <= 64 && !(cur.area < (prevArea * 0.9f)) && resident == prevAtlas
                   && prevRow != PT_ROW_RESET && S - bw > 0 && S - bh > prevRow)) break;
             const int4 aheadV = ((const int4*)g.desc)[min(i + 2, n - 1) + opaqueZero];
             unsigned long long pre = 0ull;
-            if (tid < nextWords) pre = g.bits[(size_t)nxt.wordOff + tid];
+            const int32_t lane = tid & 63;
+            if (lane < nextWords) pre = g.bits[(size_t)nxt.wordOff + lane];
             const int32_t w = tid >> 4, by = tid & 15;
             const unsigned long long rowOfLane = by < bh ? sItem[half * kItemWordsSmall + by] : 0ull;
             if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
@@ -600,23 +601,25 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
             const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
             const unsigned long long open = ~(((unsigned long long)hi << 32) | lo) & validMask;
             const unsigned long long vote = __ballot(by == 0 && open != 0ull);
-            if (vote && (tid & 63) == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
+            if (vote && lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
             __syncthreads();
             const int32_t best = sBest[slot];
             ++round; slot = slot == 2u ? 0u : slot + 1u;
             if (best == 0x7fffffff) break;
-            if (tid < bh && rowOfLane)                                               /* mask_write, lightmap.c:209-230 (tid = by of group 0) */
+            /* mask_write, lightmap.c:209-230 -- by EVERY wave (lanes 0 .. bh - 1 hold the rows), and so the next chart's rows below:
+             * the same bits ORed and the same words stored four times over, so that a wave finds what it wrote itself, in its own
+             * order, and the round's one barrier above is the only one a chart needs */
+            if (lane < bh && rowOfLane)
             {
                 const int32_t wi = best >> 6, sh = best & 63;
-                unsigned long long* arow = sAtlas + (prevRow + tid) * rowWords;
+                unsigned long long* arow = sAtlas + (prevRow + lane) * rowWords;
                 atomicOr(&arow[wi], rowOfLane << sh);
                 if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], rowOfLane >> (64 - sh));
             }
             dirty = true;
             if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = prevRow; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
             half ^= 1;
-            if (tid < nextWords) sItem[half * kItemWordsSmall + tid] = pre;
-            __syncthreads();                                             /* the atlas with this chart in it, and the next chart's rows */
+            if (lane < nextWords) sItem[half * kItemWordsSmall + lane] = pre;
             cur = nxt;
             nxt.bw = __builtin_amdgcn_readfirstlane(aheadV.x); nxt.bh = __builtin_amdgcn_readfirstlane(aheadV.y);
             nxt.area = __int_as_float(__builtin_amdgcn_readfirstlane(aheadV.z)); nxt.wordOff = (uint32_t)__builtin_amdgcn_readfirstlane(aheadV.w);
