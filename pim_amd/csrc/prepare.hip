@@ -571,9 +571,9 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
     __syncthreads();
     for (int32_t i = 0; i < n; ++i)
     {
-        /* The common charts by the short road, as many in a row as come: no more than 16 rows and 64 columns, the search goes on in
+        /* The common charts by the short road, as many in a row as come: no more than 64 rows and 64 columns, the search goes on in
          * the atlas that is in LDS from the row of the chart before, that row has room, and the chart behind it has no more than 64 words of rows --
-         * ONE round of one candidate row, 16 groups of 16 lanes for its 16 words of columns.  A wave issues an instruction every
+         * ONE round of one candidate row, a group of lanes per word of its columns.  A wave issues an instruction every
          * fourth cycle at best, so what a chart costs is the instructions on its road: this loop has nothing of the general search
          * around it (attempts, atlases, rows, units, swaps) and its state stays out of the way in between.  A chart it cannot take,
          * or for which the round finds nothing, is left untouched for the general search below (a round was spent). */
@@ -581,27 +581,39 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
         {
             const int32_t bw = cur.bw, bh = cur.bh;
             const int32_t nextWords = nxt.bh * ((nxt.bw + 63) >> 6);
-            if (!(bw <= 64 && bh <= 16 && i + 1 < n && nextWords <= 64 && !(cur.area < (prevArea * 0.9f)) && resident == prevAtlas
+            if (!(bw <= 64 && bh <= 64 && i + 1 < n && nextWords <= 64 && !(cur.area < (prevArea * 0.9f)) && resident == prevAtlas
                   && prevRow != PT_ROW_RESET && S - bw > 0 && S - bh > prevRow)) break;
             const int4 aheadV = ((const int4*)g.desc)[min(i + 2, n - 1) + opaqueZero];
             unsigned long long pre = 0ull;
             const int32_t lane = tid & 63;
             if (lane < nextWords) pre = g.bits[(size_t)nxt.wordOff + lane];
-            const int32_t w = tid >> 4, by = tid & 15;
+            /* groups of 16, 32 or 64 lanes by the mask's height: 16, 8 or 4 words of columns per pass, the row's 16 words in 1, 2 or 4 */
+            const int32_t gs = bh <= 16 ? 4 : (bh <= 32 ? 5 : 6);
+            const int32_t by = tid & ((1 << gs) - 1), grp = tid >> gs, groups = kAtlasBitThreads >> gs;
             const unsigned long long rowOfLane = by < bh ? sItem[half * kItemWordsSmall + by] : 0ull;
             if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
-            const int32_t nvalid = (S - bw) - 64 * w;
-            unsigned long long B = 0ull;
-            if (w < rowWords && rowOfLane)
+            for (int32_t w = grp; w < 16; w += groups)
             {
-                const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
-                B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+                const int32_t nvalid = (S - bw) - 64 * w;
+                unsigned long long B = 0ull;
+                if (w < rowWords && rowOfLane)
+                {
+                    const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
+                    B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+                }
+                const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
+                B = ((unsigned long long)hi << 32) | lo;
+                if (gs >= 5) B |= __shfl_xor(B, 16);
+                if (gs == 6) B |= __shfl_xor(B, 32);
+                const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
+                const unsigned long long open = ~B & validMask;
+                const unsigned long long vote = __ballot(by == 0 && open != 0ull);
+                if (vote)                                                          /* a wave's groups and passes are in column order */
+                {
+                    if (lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
+                    break;
+                }
             }
-            const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
-            const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
-            const unsigned long long open = ~(((unsigned long long)hi << 32) | lo) & validMask;
-            const unsigned long long vote = __ballot(by == 0 && open != 0ull);
-            if (vote && lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
             __syncthreads();
             const int32_t best = sBest[slot];
             ++round; slot = slot == 2u ? 0u : slot + 1u;
