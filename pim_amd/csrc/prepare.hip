@@ -591,32 +591,39 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
             const int32_t gs = bh <= 16 ? 4 : (bh <= 32 ? 5 : 6);
             const int32_t by = tid & ((1 << gs) - 1), grp = tid >> gs, groups = kAtlasBitThreads >> gs;
             const unsigned long long rowOfLane = by < bh ? sItem[half * kItemWordsSmall + by] : 0ull;
-            if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
-            for (int32_t w = grp; w < 16; w += groups)
+            /* the row of the chart before, then up to eleven rows below it, a round each (the candidates in the reference's order): a
+             * strip of the atlas that is full sends its next chart a row or two down, and that chart stays on this road */
+            int32_t best = 0x7fffffff, row = prevRow;
+            for (int32_t down = 0; down < 12 && S - bh > row; ++down, ++row)
             {
-                const int32_t nvalid = (S - bw) - 64 * w;
-                unsigned long long B = 0ull;
-                if (w < rowWords && rowOfLane)
+                if (tid == 0) sBest[slot == 2u ? 0u : slot + 1u] = 0x7fffffff;
+                for (int32_t w = grp; w < 16; w += groups)
                 {
-                    const unsigned long long* arow = sAtlas + (prevRow + by) * rowWords;
-                    B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+                    const int32_t nvalid = (S - bw) - 64 * w;
+                    unsigned long long B = 0ull;
+                    if (w < rowWords && rowOfLane)
+                    {
+                        const unsigned long long* arow = sAtlas + (row + by) * rowWords;
+                        B = blocked_columns(arow[w], (w + 1 < rowWords) ? arow[w + 1] : 0ull, rowOfLane);
+                    }
+                    const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
+                    B = ((unsigned long long)hi << 32) | lo;
+                    if (gs >= 5) B |= __shfl_xor(B, 16);
+                    if (gs == 6) B |= __shfl_xor(B, 32);
+                    const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
+                    const unsigned long long open = ~B & validMask;
+                    const unsigned long long vote = __ballot(by == 0 && open != 0ull);
+                    if (vote)                                                          /* a wave's groups and passes are in column order */
+                    {
+                        if (lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
+                        break;
+                    }
                 }
-                const uint32_t lo = row16_or((uint32_t)B), hi = row16_or((uint32_t)(B >> 32));
-                B = ((unsigned long long)hi << 32) | lo;
-                if (gs >= 5) B |= __shfl_xor(B, 16);
-                if (gs == 6) B |= __shfl_xor(B, 32);
-                const unsigned long long validMask = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
-                const unsigned long long open = ~B & validMask;
-                const unsigned long long vote = __ballot(by == 0 && open != 0ull);
-                if (vote)                                                          /* a wave's groups and passes are in column order */
-                {
-                    if (lane == __ffsll((long long)vote) - 1) atomicMin(&sBest[slot], 64 * w + __builtin_ctzll(open));
-                    break;
-                }
+                __syncthreads();
+                best = sBest[slot];
+                ++round; slot = slot == 2u ? 0u : slot + 1u;
+                if (best != 0x7fffffff) break;
             }
-            __syncthreads();
-            const int32_t best = sBest[slot];
-            ++round; slot = slot == 2u ? 0u : slot + 1u;
             if (best == 0x7fffffff) break;
             /* mask_write, lightmap.c:209-230 -- by EVERY wave (lanes 0 .. bh - 1 hold the rows), and so the next chart's rows below:
              * the same bits ORed and the same words stored four times over, so that a wave finds what it wrote itself, in its own
@@ -624,12 +631,13 @@ __global__ __launch_bounds__(kAtlasBitThreads) void k_atlas_place_bits(AtlasBitA
             if (lane < bh && rowOfLane)
             {
                 const int32_t wi = best >> 6, sh = best & 63;
-                unsigned long long* arow = sAtlas + (prevRow + lane) * rowWords;
+                unsigned long long* arow = sAtlas + (row + lane) * rowWords;
                 atomicOr(&arow[wi], rowOfLane << sh);
                 if (sh && wi + 1 < rowWords) atomicOr(&arow[wi + 1], rowOfLane >> (64 - sh));
             }
             dirty = true;
-            if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = prevRow; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
+            if (tid == 0) { a.translations[2 * i] = best; a.translations[2 * i + 1] = row; a.atlasIndex[i] = prevAtlas; atomicAdd(&a.atlasCharts[prevAtlas], 1); }
+            prevRow = row;
             half ^= 1;
             if (lane < nextWords) sItem[half * kItemWordsSmall + lane] = pre;
             cur = nxt;
